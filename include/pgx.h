@@ -1,0 +1,141 @@
+/*
+ * pgx.h -- C ABI of libpgx.so: MI355X (gfx950) native dewarp -> FAST-like detect -> NMS ->
+ * BRIEF -> all-pairs Hamming match with the reference's greedy one-to-one assignment.
+ *
+ * This is the drop-in boundary for the hot path of Takatsuka-Mark/Photogrammetry
+ * (dotnet_src/ImageProcessing).  The reference has no FFI today; every entry
+ * point below names the C# member it replaces, and INTEGRATION.md shows the [DllImport]
+ * stubs a maintainer would add.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - Images are row-major [H][W]; pixel (x, y) = column x, row y = the reference's
+ *     Matrix<T>[x, y] (Math/LinearAlgebra/Matrix.cs:44-76).
+ *   - Rgba64 pixel = 4 x uint16 {R,G,B,A} (Images.Abstractions/Pixels/Rgba64.cs:3-9).
+ *   - A descriptor is ceil(P/32) little-endian uint32 words of the reference's BigInteger:
+ *     bit b of the BigInteger is bit (b & 31) of word (b >> 5); BRIEF test pair p lands on
+ *     bit P-1-p (ImageProcessing.Abstractions/Keypoint.cs:29-57).
+ *   - Every function returns PGX_OK or a PGX_E_* code; pgx_last_error() gives the text.
+ *     No C++ exception crosses this boundary.
+ *   - "host" entry points take host pointers, copy in/out and return when the result is in
+ *     the caller's buffer.  "_dev" entry points take DEVICE pointers, enqueue on the
+ *     context's stream and return immediately; data errors surface in pgx_check_status().
+ *   - The caller owns every buffer; the library keeps no caller pointer after a call returns.
+ *   - One context per GPU.  Calls on one context are serialised by an internal mutex
+ *     (the reference never re-enters a stage: TestService.cs:25,137-152).
+ */
+#ifndef PGX_H
+#define PGX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGX_OK               0
+#define PGX_E_DIM_MISMATCH   1  /* ArgumentException            DeWarp.cs:22-23           */
+#define PGX_E_OOB_SOURCE     2  /* IndexOutOfRangeException     Matrix.cs:63-66,204-209   */
+#define PGX_E_EMPTY_SET      3  /* ArgumentOutOfRangeException  KeypointMatching.cs:61    */
+#define PGX_E_CAPACITY       4  /* an output or workspace capacity was exceeded           */
+#define PGX_E_BADARG         5  /* ArgumentException / null pointer / unsupported size    */
+#define PGX_E_HIP            6  /* a HIP runtime call failed                              */
+#define PGX_E_NOT_CONFIGURED 7  /* stage used before its pgx_set_* call                   */
+
+#define PGX_DIST_NONE 2147483647 /* int.MaxValue: tail entries when N1 > N2 (KeypointMatching.cs:40-42) */
+
+typedef struct pgx_ctx pgx_ctx;
+
+/* Keypoint{Coordinate, FastScore, Value} (ImageProcessing.Abstractions/Keypoint.cs:11-15);
+ * the BriefDescriptor travels in a separate [N][words] array. */
+typedef struct { int32_t x, y, fast_score; float value; } pgx_keypoint;
+
+/* KeypointPair{Keypoint1, Keypoint2, Distance} as indices into the two input lists
+ * (ImageProcessing.Abstractions/KeypointPair.cs:3-8). */
+typedef struct { int32_t k1, k2, dist; } pgx_pair;
+
+/* ---- context ------------------------------------------------------------------------ */
+int  pgx_ctx_create(int device, pgx_ctx **out);
+void pgx_ctx_destroy(pgx_ctx *ctx);
+const char *pgx_last_error(pgx_ctx *ctx);
+const char *pgx_version(void);
+/* Use the caller's HIP stream (hipStream_t) for all work; NULL = the context's own stream. */
+int  pgx_set_stream(pgx_ctx *ctx, void *hip_stream);
+/* Wait for the stream and report the first data error of the "_dev" calls since the last check. */
+int  pgx_check_status(pgx_ctx *ctx);
+
+/* ---- init-time configuration (replaces DI-bound options, Program.cs:61-69) ----------- */
+/* DeWarpTransformStepFactory.Initialize (DeWarpTransformStepFactory.cs:26-31): the Matrix<Uv>
+ * built by DeWarp.GetDistortionMatrix, as host int32 [H][W][2] = (U, V).  NULL = stage off. */
+int pgx_set_dewarp_map(pgx_ctx *ctx, const int32_t *uv, int W, int H);
+/* KeypointDetection ctor's _gaussianKeypairs (KeypointDetection.cs:35-39): host int32 [P][4] =
+ * (x1, y1, x2, y2).  The table is an INPUT because the reference draws it unseeded. */
+int pgx_set_brief_pairs(pgx_ctx *ctx, const int32_t *pairs, int P);
+/* KeypointDetectionOptions.Threshold, RedundantKeypointEliminationOptions.SuppressionRadius. */
+int pgx_set_detect_params(pgx_ctx *ctx, float threshold, int suppression_radius);
+/* Per-frame capacities of the fused detect path: raw FAST hits kept for NMS, and survivors. */
+int pgx_set_capacity(pgx_ctx *ctx, int max_raw_per_frame, int max_keypoints_per_frame);
+
+/* ---- stage-granular host entry points (one reference function each) ------------------ */
+/* DeWarp.ApplyDistortionMat<Rgba64> (DeWarp.cs:19-37) with the context's map. */
+int pgx_dewarp(pgx_ctx *ctx, const uint16_t *rgba64, int W, int H, uint16_t *out_rgba64);
+/* Matrix.Convert(Grayscale.FromRgba64) (Converters.cs:15-22, Grayscale.cs:19-23). */
+int pgx_gray(pgx_ctx *ctx, const uint16_t *rgba64, int W, int H, float *out_gray);
+/* KeypointDetection.Detect minus the BRIEF ctor work (KeypointDetection.cs:42-63): raster-order
+ * hits.  *n_out = total hits; only min(*n_out, capacity) are written (PGX_E_CAPACITY if more). */
+int pgx_fast(pgx_ctx *ctx, const float *gray, int W, int H,
+             pgx_keypoint *out, int capacity, int *n_out);
+/* Keypoint.GetBriefDescriptor (Keypoint.cs:29-57) for n keypoints -> desc [n][ceil(P/32)]. */
+int pgx_brief(pgx_ctx *ctx, const float *gray, int W, int H,
+              const pgx_keypoint *kps, int n, uint32_t *desc_out);
+/* RedundantKeypointEliminator.EliminateRedundantKeypoints (:16-35): order_out[k] = index into
+ * kps of the k-th accepted keypoint; *n_out = accepted count (order_out holds n entries). */
+int pgx_nms(pgx_ctx *ctx, const pgx_keypoint *kps, int n, int W, int H,
+            int32_t *order_out, int *n_out);
+/* KeypointMatching.MatchKeypoints (KeypointMatching.cs:14-69): exactly n1 entries in the
+ * reference's emission order; (0, 0, PGX_DIST_NONE) tail when n1 > n2; PGX_E_EMPTY_SET when
+ * n2 == 0 < n1.  words = uint32 words per descriptor. */
+int pgx_match(pgx_ctx *ctx, const uint32_t *desc1, int n1, const uint32_t *desc2, int n2,
+              int words, pgx_pair *out);
+
+/* ---- fused host entry point: dewarp -> gray -> detect -> NMS -> BRIEF for one image ---- */
+/* The chain of TestService.BuildKeypointDetectorPipeline (TestService.cs:137-152).
+ * kp_out [capacity], desc_out [capacity][ceil(P/32)]; *n_out survivors in NMS order,
+ * *n_raw raw FAST hits. */
+int pgx_detect(pgx_ctx *ctx, const uint16_t *rgba64, int W, int H,
+               pgx_keypoint *kp_out, uint32_t *desc_out, int capacity, int *n_out, int *n_raw);
+
+/* ---- device-resident batched entry points (asynchronous on the context's stream) ------ */
+/* F frames [F][H][W][4] uint16 in HBM -> per frame up to `capacity` survivors.
+ * d_kp [F][capacity], d_desc [F][capacity][words], d_counts [F], d_nraw [F] (all device). */
+int pgx_detect_batch_dev(pgx_ctx *ctx, const uint16_t *d_rgba64, int F, int W, int H,
+                         pgx_keypoint *d_kp, uint32_t *d_desc, int32_t *d_counts,
+                         int32_t *d_nraw, int capacity);
+/* M image pairs: d_pairlist [M][2] = (frame_a, frame_b) indexes descriptor sets
+ * d_desc [F][stride][words] with d_counts [F].  d_out [M][stride]: the first counts[a] entries of
+ * row m are the reference's match list for (a, b).  Pairs with counts[b] == 0 < counts[a] raise
+ * PGX_E_EMPTY_SET in pgx_check_status and leave their row filled with (0,0,PGX_DIST_NONE). */
+int pgx_match_batch_dev(pgx_ctx *ctx, const uint32_t *d_desc, const int32_t *d_counts,
+                        int stride, int words, const int32_t *d_pairlist, int M, pgx_pair *d_out);
+
+/* ---- measurement hooks (bench.py) ---------------------------------------------------- */
+/* When on, the named hot kernels are bracketed by HIP events on the launch stream. */
+int pgx_profile_enable(pgx_ctx *ctx, int on);
+/* Sums since the last reset for kernel `name` ("dewarp_gray", "fast", "ham_argmin", ...):
+ * launches and total milliseconds.  Synchronises the stream. */
+int pgx_profile_get(pgx_ctx *ctx, const char *name, int *launches, double *total_ms);
+int pgx_profile_reset(pgx_ctx *ctx);
+/* Counters of the last pgx_match* call: greedy rounds run on the MFMA path and the number of
+ * descriptor-pair distance evaluations issued (sum over rounds of n1*n2). */
+int pgx_match_stats(pgx_ctx *ctx, int *rounds_mfma, int64_t *evaluations);
+
+/* ---- host-side helpers (no GPU work) -------------------------------------------------- */
+/* Utils.NextGaussianPair (Utils.cs:14-38) on a seeded splitmix64 stream; out [P][4]. */
+int pgx_make_brief_pairs(uint64_t seed, int sigma, int P, int32_t *out);
+/* DeWarp.GetDistortionMatrix (DeWarp.cs:39-107) in float64 on the host; out [H][W][2].
+ * MathNet's Cubic.RealRoots is restated from its published algorithm (parity unpinned). */
+int pgx_build_dewarp_map(int W, int H, const double *coeffs, int ncoeffs, int32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGX_H */

@@ -1,0 +1,277 @@
+"""Host-side mirror of the reference's ImageProcessing classes over the C ABI (include/pgx.h).
+
+The reference's seam is "concrete class method called from a Dataflow block" (SURVEY D1):
+DeWarp.ApplyDistortionMat, Grayscale.FromRgba64 (via Matrix.Convert), KeypointDetection.Detect,
+RedundantKeypointEliminator.EliminateRedundantKeypoints, KeypointMatching.MatchKeypoints.
+The classes below keep those names, argument meanings and error behaviour (the .NET exception
+types are mirrored by the exception classes here) so that tests read like the reference's own.
+All arithmetic happens in libpgx.so on the GPU; numpy arrays are only the marshalling format.
+The C++ twin of this file (for a compiled host) is photogrammetry_amd/host/pgx_host.hpp.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (PGX_DIST_NONE, PGX_E_BADARG, PGX_E_CAPACITY, PGX_E_DIM_MISMATCH, PGX_E_EMPTY_SET,
+                   PGX_E_HIP, PGX_E_NOT_CONFIGURED, PGX_E_OOB_SOURCE, PGX_OK)
+
+KEYPOINT_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("fast_score", "<i4"), ("value", "<f4")])
+PAIR_DTYPE = np.dtype([("k1", "<i4"), ("k2", "<i4"), ("dist", "<i4")])
+
+
+class PgxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("pgx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ArgumentException(PgxError, ValueError):
+    """System.ArgumentException (DeWarp.cs:23, :48)."""
+
+
+class IndexOutOfRangeException(PgxError, IndexError):
+    """System.IndexOutOfRangeException (Matrix.cs:65, :207)."""
+
+
+class ArgumentOutOfRangeException(PgxError, IndexError):
+    """System.ArgumentOutOfRangeException (KeypointMatching.cs:61 with an empty keypoints2)."""
+
+
+class CapacityError(PgxError):
+    pass
+
+
+_EXC = {PGX_E_DIM_MISMATCH: ArgumentException, PGX_E_BADARG: ArgumentException,
+        PGX_E_OOB_SOURCE: IndexOutOfRangeException, PGX_E_EMPTY_SET: ArgumentOutOfRangeException,
+        PGX_E_CAPACITY: CapacityError}
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+def _dptr(t):
+    """Device pointer of a torch tensor (or a raw int)."""
+    return C.c_void_p(t if isinstance(t, int) else t.data_ptr())
+
+
+class Engine:
+    """One pgx context = one GPU (pgx_ctx_create).  Thin, 1:1 with the C ABI."""
+
+    def __init__(self, device=0):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        rc = self._L.pgx_ctx_create(int(device), C.byref(h))
+        if rc != PGX_OK:
+            raise PgxError(rc, "pgx_ctx_create(device=%d) failed: no usable gfx950 device "
+                               "(this package has no CPU fallback)" % device)
+        self._h = h
+        self.device = device
+        self.words = 0
+        self.P = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pgx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != PGX_OK:
+            msg = self._L.pgx_last_error(self._h).decode()
+            raise _EXC.get(rc, PgxError)(rc, msg)
+
+    # -- configuration ------------------------------------------------------------------
+    def set_stream(self, stream_handle):
+        self._chk(self._L.pgx_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def check_status(self):
+        self._chk(self._L.pgx_check_status(self._h))
+
+    def set_dewarp_map(self, map_uv):
+        if map_uv is None:
+            self._chk(self._L.pgx_set_dewarp_map(self._h, None, 0, 0))
+            return
+        m = np.ascontiguousarray(map_uv, dtype=np.int32)
+        assert m.ndim == 3 and m.shape[2] == 2
+        self._chk(self._L.pgx_set_dewarp_map(self._h, _ptr(m), m.shape[1], m.shape[0]))
+
+    def set_brief_pairs(self, pairs):
+        p = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 4)
+        self._chk(self._L.pgx_set_brief_pairs(self._h, _ptr(p), p.shape[0]))
+        self.P = p.shape[0]
+        self.words = (self.P + 31) // 32
+
+    def set_detect_params(self, threshold, suppression_radius):
+        self._chk(self._L.pgx_set_detect_params(self._h, C.c_float(threshold), int(suppression_radius)))
+
+    def set_capacity(self, max_raw_per_frame, max_keypoints_per_frame):
+        self._chk(self._L.pgx_set_capacity(self._h, int(max_raw_per_frame), int(max_keypoints_per_frame)))
+
+    # -- stage-granular host API ----------------------------------------------------------
+    def dewarp(self, rgba64):
+        a = np.ascontiguousarray(rgba64, dtype=np.uint16)
+        out = np.empty_like(a)
+        self._chk(self._L.pgx_dewarp(self._h, _ptr(a), a.shape[1], a.shape[0], _ptr(out)))
+        return out
+
+    def gray(self, rgba64):
+        a = np.ascontiguousarray(rgba64, dtype=np.uint16)
+        out = np.empty(a.shape[:2], dtype=np.float32)
+        self._chk(self._L.pgx_gray(self._h, _ptr(a), a.shape[1], a.shape[0], _ptr(out)))
+        return out
+
+    def fast(self, gray, capacity=None):
+        g = np.ascontiguousarray(gray, dtype=np.float32)
+        cap = int(capacity) if capacity is not None else max(1, g.size)
+        out = np.zeros(cap, dtype=KEYPOINT_DTYPE)
+        n = C.c_int(0)
+        self._chk(self._L.pgx_fast(self._h, _ptr(g), g.shape[1], g.shape[0], _ptr(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def brief(self, gray, kps):
+        g = np.ascontiguousarray(gray, dtype=np.float32)
+        k = np.ascontiguousarray(kps, dtype=KEYPOINT_DTYPE)
+        out = np.zeros((len(k), self.words), dtype=np.uint32)
+        self._chk(self._L.pgx_brief(self._h, _ptr(g), g.shape[1], g.shape[0], _ptr(k), len(k), _ptr(out)))
+        return out
+
+    def nms(self, kps, W, H):
+        k = np.ascontiguousarray(kps, dtype=KEYPOINT_DTYPE)
+        order = np.zeros(max(1, len(k)), dtype=np.int32)
+        n = C.c_int(0)
+        self._chk(self._L.pgx_nms(self._h, _ptr(k), len(k), int(W), int(H), _ptr(order), C.byref(n)))
+        return order[:n.value].copy()
+
+    def match(self, desc1, desc2):
+        d1 = np.ascontiguousarray(desc1, dtype=np.uint32)
+        d2 = np.ascontiguousarray(desc2, dtype=np.uint32)
+        words = d1.shape[1] if d1.ndim == 2 and d1.shape[0] else (d2.shape[1] if d2.ndim == 2 and d2.shape[0] else 8)
+        out = np.zeros(max(1, len(d1)), dtype=PAIR_DTYPE)
+        self._chk(self._L.pgx_match(self._h, _ptr(d1), len(d1), _ptr(d2), len(d2), int(words), _ptr(out)))
+        return out[:len(d1)].copy()
+
+    def detect(self, rgba64, capacity=8192):
+        a = np.ascontiguousarray(rgba64, dtype=np.uint16)
+        kp = np.zeros(capacity, dtype=KEYPOINT_DTYPE)
+        desc = np.zeros((capacity, max(1, self.words)), dtype=np.uint32)
+        n, nraw = C.c_int(0), C.c_int(0)
+        self._chk(self._L.pgx_detect(self._h, _ptr(a), a.shape[1], a.shape[0], _ptr(kp), _ptr(desc), int(capacity),
+                                     C.byref(n), C.byref(nraw)))
+        return kp[:n.value].copy(), desc[:n.value].copy(), nraw.value
+
+    # -- device-resident batched API (torch tensors or raw device pointers) -------------------
+    def detect_batch_dev(self, d_rgba64, F, W, H, d_kp, d_desc, d_counts, d_nraw, capacity):
+        self._chk(self._L.pgx_detect_batch_dev(self._h, _dptr(d_rgba64), int(F), int(W), int(H), _dptr(d_kp),
+                                               _dptr(d_desc), _dptr(d_counts), _dptr(d_nraw), int(capacity)))
+
+    def match_batch_dev(self, d_desc, d_counts, stride, words, d_pairlist, M, d_out):
+        self._chk(self._L.pgx_match_batch_dev(self._h, _dptr(d_desc), _dptr(d_counts), int(stride), int(words),
+                                              _dptr(d_pairlist), int(M), _dptr(d_out)))
+
+    # -- measurement ------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self._L.pgx_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self._L.pgx_profile_reset(self._h))
+
+    def profile_get(self, name):
+        n, ms = C.c_int(0), C.c_double(0.0)
+        self._chk(self._L.pgx_profile_get(self._h, name.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
+def make_brief_pairs(seed, sigma, P):
+    """Seeded table with the reference's generator formula (Utils.cs:14-38)."""
+    out = np.zeros((P, 4), dtype=np.int32)
+    rc = _lib.lib().pgx_make_brief_pairs(C.c_uint64(seed), int(sigma), int(P), _ptr(out))
+    if rc != PGX_OK:
+        raise PgxError(rc, "pgx_make_brief_pairs")
+    return out
+
+
+def build_dewarp_map(W, H, coeffs):
+    """DeWarp.GetDistortionMatrix (DeWarp.cs:39-107) -> int32 [H][W][2]."""
+    k = np.ascontiguousarray(coeffs, dtype=np.float64)
+    out = np.zeros((H, W, 2), dtype=np.int32)
+    rc = _lib.lib().pgx_build_dewarp_map(int(W), int(H), _ptr(k), len(k), _ptr(out))
+    if rc != PGX_OK:
+        raise ArgumentException(rc, "You must pass exactly 5 distortion coefficients")
+    return out
+
+
+# ---- the reference's classes --------------------------------------------------------------------
+
+class DeWarp:
+    """ImageProcessing/DeWarp.cs.  Options: MatrixDimensions (W, H), DistortionCoefficients[5]."""
+
+    def __init__(self, engine, width, height, distortion_coefficients):
+        self._e = engine
+        self.width, self.height = int(width), int(height)
+        self.coeffs = list(distortion_coefficients)
+
+    def GetDistortionMatrix(self):
+        return build_dewarp_map(self.width, self.height, self.coeffs)
+
+    def ApplyDistortionMat(self, image_rgba64, distortion_matrix):
+        """DeWarp.cs:19-37.  ArgumentException on size mismatch, IndexOutOfRangeException on an
+        out-of-image source coordinate."""
+        self._e.set_dewarp_map(distortion_matrix)
+        return self._e.dewarp(image_rgba64)
+
+
+class Grayscale:
+    """Images.Abstractions/Pixels/Grayscale.cs:19-23 applied through Matrix.Convert."""
+
+    def __init__(self, engine):
+        self._e = engine
+
+    def FromRgba64(self, image_rgba64):
+        return self._e.gray(image_rgba64)
+
+
+class KeypointDetection:
+    """ImageProcessing/KeypointDetection.cs.  Options: Threshold, (GaussianStandardDeviation,
+    NumGaussianPairs -> here the explicit pair table)."""
+
+    def __init__(self, engine, threshold, gaussian_pairs, suppression_radius=0):
+        self._e = engine
+        engine.set_detect_params(threshold, suppression_radius)
+        engine.set_brief_pairs(gaussian_pairs)
+
+    def Detect(self, gray):
+        """KeypointDetection.cs:42-63 -> (keypoints, descriptors) in raster order."""
+        kps = self._e.fast(gray)
+        return kps, self._e.brief(gray, kps)
+
+
+class RedundantKeypointEliminator:
+    """ImageProcessing/RedundantKeypointEliminator.cs.  Option: SuppressionRadius."""
+
+    def __init__(self, engine, suppression_radius, threshold=0.0):
+        self._e = engine
+        self._r = int(suppression_radius)
+        self._t = threshold
+
+    def EliminateRedundantKeypoints(self, keypoints, width, height):
+        """Returns the indices of the accepted keypoints in acceptance order (:16-35)."""
+        self._e.set_detect_params(self._t, self._r)
+        return self._e.nms(keypoints, width, height)
+
+
+class KeypointMatching:
+    """ImageProcessing/KeypointMatching.cs."""
+
+    def __init__(self, engine):
+        self._e = engine
+
+    def MatchKeypoints(self, descriptors1, descriptors2):
+        """KeypointMatching.cs:14-69 -> PAIR_DTYPE[n1] (indices + Hamming distance)."""
+        return self._e.match(descriptors1, descriptors2)

@@ -1,0 +1,192 @@
+// k_fast.hip -- the reference's FAST-like segment test + raster-order compaction, gfx950.
+//
+// Reference: ImageProcessing/KeypointDetection.cs:42-138 with its three quirks kept
+// (SURVEY D7): ring entry 15 is (-3,+1) again, "different" is |delta| >= T in either
+// direction, FastScore = longest circular run of "different" samples (12..16).
+//
+// Bit formulation (equivalent to the C# state machine, checked against the oracle):
+//   S = 16-bit mask of "similar" ring samples.  The pre-test (<= 1 similar among entries
+//   0,4,8,12) and the "fifth similar rejects" rule are both implied by "longest run >= 12",
+//   so score = longest circular run of zero bits of S if that is >= 12, else none.
+//
+// HBM-bound: 4 B/px grey read (+ 0.5 B/px of ballot planes written).  Three launches:
+//   k_fast_planes   64x16-pixel tiles staged through LDS (halo 3); one wave per 4 tile rows,
+//                   one lane per pixel; per 64-pixel row segment three 64-bit ballots of the
+//                   score bits + the count -> seg[F][H][ntx][4]
+//   k_seg_scan      one workgroup per frame: exclusive scan of the counts in (y, tx) order
+//                   = raster order; n_raw[f]
+//   k_fast_compact  one wave per segment: rank = popcount(mask below lane) -> raw_xy/raw_score
+#include "pgx_internal.h"
+
+namespace {
+
+constexpr int TW = 64, TH = 16, HALO = 3;
+constexpr int LROWS = TH + 2 * HALO;  // 22
+constexpr int LSTRIDE = 72;           // >= 70, keeps rows 16-B aligned
+
+__global__ __launch_bounds__(256) void k_fast_planes(const float *__restrict__ gray, int W, int H, float T,
+                                                     unsigned long long *__restrict__ seg, int ntx)
+{
+    __shared__ float tile[LROWS][LSTRIDE];
+    const int tx = blockIdx.x, ty = blockIdx.y, f = blockIdx.z;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float *g = gray + (size_t)f * W * H;
+    const int x0 = tx * TW - HALO, y0 = ty * TH - HALO;
+
+    for (int r = wv; r < LROWS; r += 4) {
+        const int gy = y0 + r;
+        const bool rowok = gy >= 0 && gy < H;
+        const float *grow = g + (size_t)(rowok ? gy : 0) * W;
+        int gx = x0 + lane;
+        tile[r][lane] = (rowok && gx >= 0 && gx < W) ? grow[gx] : 0.0f;
+        if (lane < 2 * HALO) {
+            gx = x0 + 64 + lane;
+            tile[r][64 + lane] = (rowok && gx < W) ? grow[gx] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    const int x = tx * TW + lane;
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        const int ry = wv * 4 + k;
+        const int y = ty * TH + ry;
+        if (y >= H) break; // wave-uniform
+        int score = 0;
+        if (x >= 3 && x < W - 3 && y >= 3 && y < H - 3) { // KeypointDetection.cs:45-47
+            const float c = tile[ry + 3][lane + 3];
+            const float lo = __fsub_rn(c, T), hi = __fadd_rn(c, T); // :137, one rounding each
+#define PGX_SIM(dx, dy) ((tile[ry + 3 + (dy)][lane + 3 + (dx)] > lo) & (tile[ry + 3 + (dy)][lane + 3 + (dx)] < hi))
+            // cheap reject first: the four compass samples (:116-133)
+            const unsigned s0 = PGX_SIM(-3, 0), s4 = PGX_SIM(0, 3), s8 = PGX_SIM(3, 0), s12 = PGX_SIM(0, -3);
+            if (s0 + s4 + s8 + s12 <= 1u) {
+                unsigned S = s0 | (s4 << 4) | (s8 << 8) | (s12 << 12);
+                const unsigned s1 = PGX_SIM(-3, 1);
+                S |= s1 << 1;
+                S |= (unsigned)PGX_SIM(-2, 2) << 2;
+                S |= (unsigned)PGX_SIM(-1, 3) << 3;
+                S |= (unsigned)PGX_SIM(1, 3) << 5;
+                S |= (unsigned)PGX_SIM(2, 2) << 6;
+                S |= (unsigned)PGX_SIM(3, 1) << 7;
+                S |= (unsigned)PGX_SIM(3, -1) << 9;
+                S |= (unsigned)PGX_SIM(2, -2) << 10;
+                S |= (unsigned)PGX_SIM(1, -3) << 11;
+                S |= (unsigned)PGX_SIM(-1, -3) << 13;
+                S |= (unsigned)PGX_SIM(-2, -2) << 14;
+                S |= s1 << 15; // entry 15 = (-3, 1) again (:18)
+#undef PGX_SIM
+                if (S == 0u) {
+                    score = 16;
+                } else {
+                    const unsigned D = ~S & 0xFFFFu;
+                    const unsigned dd = D | (D << 16);
+                    const unsigned x1 = dd & (dd >> 1);
+                    const unsigned x2 = x1 & (x1 >> 2);
+                    const unsigned x3 = x2 & (x2 >> 4);
+                    const unsigned t12 = x3 & (x2 >> 8);
+                    if (t12) {
+                        const unsigned t13 = t12 & (dd >> 12);
+                        const unsigned t14 = t13 & (dd >> 13);
+                        const unsigned t15 = t14 & (dd >> 14);
+                        score = 12 + (t13 != 0u) + (t14 != 0u) + (t15 != 0u);
+                    }
+                }
+            }
+        }
+        const int code = score ? score - 11 : 0; // 1..5
+        const unsigned long long b0 = __ballot(code & 1), b1 = __ballot(code & 2), b2 = __ballot(code & 4);
+        if (lane == 0) {
+            unsigned long long *o = seg + (((size_t)f * H + y) * ntx + tx) * 4;
+            const unsigned long long any = b0 | b1 | b2;
+            *reinterpret_cast<ulonglong2 *>(o) = make_ulonglong2(b0, b1);
+            *reinterpret_cast<ulonglong2 *>(o + 2) = make_ulonglong2(b2, (unsigned long long)__popcll(any));
+        }
+    }
+}
+
+// exclusive scan of per-segment counts, one 1024-thread workgroup per frame
+__global__ __launch_bounds__(1024) void k_seg_scan(const unsigned long long *__restrict__ seg, int nseg,
+                                                   uint32_t *__restrict__ segoff, int32_t *__restrict__ n_raw,
+                                                   int raw_cap, int *status)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int f = blockIdx.x;
+    const unsigned long long *sg = seg + (size_t)f * nseg * 4;
+    uint32_t *so = segoff + (size_t)f * nseg;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nseg; base += 1024 * 4) {
+        // each thread owns 4 consecutive segments
+        const int i0 = base + tid * 4;
+        uint32_t c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) c[k] = (i0 + k < nseg) ? (uint32_t)sg[(size_t)(i0 + k) * 4 + 3] : 0u;
+        uint32_t tsum = c[0] + c[1] + c[2] + c[3];
+        uint32_t incl = tsum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wv; w++) woff += wsum[w];
+        uint32_t run = carry_s + woff + incl - tsum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < nseg) so[i0 + k] = run;
+            run += c[k];
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = run;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        n_raw[f] = (int32_t)carry_s;
+        if ((int)carry_s > raw_cap) atomicOr(status, (int)PGX_ST_RAW_CAP);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fast_compact(const unsigned long long *__restrict__ seg,
+                                                      const uint32_t *__restrict__ segoff, int H, int ntx,
+                                                      uint32_t *__restrict__ raw_xy, int32_t *__restrict__ raw_score,
+                                                      int raw_cap)
+{
+    const int f = blockIdx.y;
+    const int nseg = H * ntx;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= nseg) return;
+    const unsigned long long *sg = seg + ((size_t)f * nseg + s) * 4;
+    const unsigned long long b0 = sg[0], b1 = sg[1], b2 = sg[2];
+    const unsigned long long any = b0 | b1 | b2;
+    if (!((any >> lane) & 1ull)) return;
+    const uint32_t base = segoff[(size_t)f * nseg + s];
+    const uint32_t pos = base + (uint32_t)__popcll(any & ((1ull << lane) - 1ull));
+    if (pos >= (uint32_t)raw_cap) return;
+    const int y = s / ntx, tx = s - y * ntx;
+    const int x = tx * 64 + lane;
+    const int code = (int)((b0 >> lane) & 1ull) | ((int)((b1 >> lane) & 1ull) << 1) | ((int)((b2 >> lane) & 1ull) << 2);
+    raw_xy[(size_t)f * raw_cap + pos] = ((uint32_t)y << 16) | (uint32_t)x;
+    raw_score[(size_t)f * raw_cap + pos] = code + 11;
+}
+
+} // namespace
+
+size_t pgx_fast_seg_count(int W, int H) { return (size_t)H * ((W + TW - 1) / TW); }
+
+void pgx_launch_fast(hipStream_t s, const float *gray, int F, int W, int H, float T,
+                     unsigned long long *seg, uint32_t *segoff, int32_t *n_raw, uint32_t *raw_xy,
+                     int32_t *raw_score, int raw_cap, int *status)
+{
+    if (F <= 0 || W <= 0 || H <= 0) return;
+    const int ntx = (W + TW - 1) / TW, nty = (H + TH - 1) / TH;
+    const int nseg = H * ntx;
+    hipLaunchKernelGGL(k_fast_planes, dim3(ntx, nty, F), dim3(256), 0, s, gray, W, H, T, seg, ntx);
+    hipLaunchKernelGGL(k_seg_scan, dim3(F), dim3(1024), 0, s, seg, nseg, segoff, n_raw, raw_cap, status);
+    hipLaunchKernelGGL(k_fast_compact, dim3((nseg + 3) / 4, F), dim3(256), 0, s, seg, segoff, H, ntx, raw_xy,
+                       raw_score, raw_cap);
+}

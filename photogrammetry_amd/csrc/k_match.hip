@@ -1,0 +1,384 @@
+// k_match.hip -- KeypointMatching.MatchKeypoints on gfx950.
+//
+// Reference: ImageProcessing/KeypointMatching.cs:14-69.  dist[k1][k2] = popcount(d1 ^ d2)
+// (:20-31, :71-82); then N1 times: take the first strict minimum over the still-available
+// (k1, k2) in (k1 asc, k2 asc) order, emit it, retire its row and column (:38-66).  When the
+// columns run out the loop keeps emitting (kp1[0], kp2[0], int.MaxValue) (:40-42, :57-62).
+//
+// Parallel formulation (equal to the literal loop under the strict total order
+// (dist, k1, k2), checked against the oracle): per round every available row takes
+// min_j (d, j), every available column takes min_i (d, i); an edge that is both is accepted
+// and its row and column retire.  Accepted edges sorted by (dist, k1) are the reference's
+// emission order.
+//
+// Data: keys are u32 (dist << 20 | index) so "min" carries the tie-break; per image pair the
+// available rows / columns are kept as ascending index lists that are stably compacted after
+// every round, so later rounds only evaluate what is left.
+//
+// Kernels
+//   k_match_init      identity lists, keys, counters
+//   k_ham_valu        xor+popcount distance/argmin, one thread per row, columns broadcast
+//                     from LDS; both directions in one grid (generic in `words`)
+//   k_ham_mfma        (words == 8) int8 MFMA formulation, see below
+//   k_match_select    one workgroup per image pair: accept mutual edges, compact the lists
+//   k_match_finish    one workgroup per image pair: runs the remaining rounds in-kernel, then
+//                     sorts (bitonic, LDS) and writes the N1 output entries
+#include "pgx_internal.h"
+
+namespace {
+
+constexpr int SEL_NT = 1024;
+constexpr int CNT_N1 = 0, CNT_N2 = 1, CNT_NACC = 2, CNT_N1_ORIG = 3, CNT_N2_ORIG = 4, CNT_WORDS = 8;
+
+struct PairWs {
+    uint32_t *rowkey, *colkey, *rows[2], *cols[2];
+    int32_t *mk2, *md;
+    int32_t *cnt;
+    uint32_t *skeys;
+};
+
+__host__ __device__ inline size_t pow2_ge(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
+
+__host__ __device__ inline size_t pair_ws_words(int S) { return (size_t)8 * S + CNT_WORDS + pow2_ge((size_t)(S > 1 ? S : 1)); }
+
+__device__ __forceinline__ PairWs pair_ws(uint32_t *ws, int m, int S)
+{
+    uint32_t *b = ws + (size_t)m * pair_ws_words(S);
+    PairWs p;
+    p.rowkey = b; p.colkey = b + S;
+    p.rows[0] = b + 2 * (size_t)S; p.rows[1] = b + 3 * (size_t)S;
+    p.cols[0] = b + 4 * (size_t)S; p.cols[1] = b + 5 * (size_t)S;
+    p.mk2 = reinterpret_cast<int32_t *>(b + 6 * (size_t)S);
+    p.md = reinterpret_cast<int32_t *>(b + 7 * (size_t)S);
+    p.cnt = reinterpret_cast<int32_t *>(b + 8 * (size_t)S);
+    p.skeys = b + 8 * (size_t)S + CNT_WORDS;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_match_init(uint32_t *ws, const int32_t *__restrict__ counts,
+                                                    const int32_t *__restrict__ pairlist, int S, int *status)
+{
+    const int m = blockIdx.y;
+    PairWs p = pair_ws(ws, m, S);
+    int n1 = counts[pairlist[2 * m]], n2 = counts[pairlist[2 * m + 1]];
+    n1 = n1 < 0 ? 0 : (n1 > S ? S : n1);
+    n2 = n2 < 0 ? 0 : (n2 > S ? S : n2);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
+        p.rowkey[i] = PGX_KEY_NONE;
+        p.colkey[i] = PGX_KEY_NONE;
+        p.rows[0][i] = (uint32_t)i;
+        p.cols[0][i] = (uint32_t)i;
+        p.mk2[i] = -1;
+        p.md[i] = PGX_DIST_NONE;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        p.cnt[CNT_N1] = n1; p.cnt[CNT_N2] = n2; p.cnt[CNT_NACC] = 0;
+        p.cnt[CNT_N1_ORIG] = n1; p.cnt[CNT_N2_ORIG] = n2;
+        if (n1 > 0 && n2 == 0) atomicOr(status, (int)PGX_ST_EMPTY_SET); // KeypointMatching.cs:61
+    }
+}
+
+// ---- xor + popcount distance / argmin -------------------------------------------------
+// One thread per (compact) row; a block covers RB rows and walks a chunk of columns staged
+// through LDS 256 at a time (all lanes read the same LDS address: broadcast, conflict-free).
+template <int WORDS>
+__device__ __forceinline__ void ham_rows_vs_cols(const uint32_t *__restrict__ rdesc, const uint32_t *__restrict__ rlist,
+                                                 int nR, const uint32_t *__restrict__ cdesc,
+                                                 const uint32_t *__restrict__ clist, int c_begin, int c_end,
+                                                 int r_begin, int words_rt, uint32_t *outkey, bool use_atomic,
+                                                 uint32_t *lds /* [256*(W+1)] */)
+{
+    const int W = WORDS > 0 ? WORDS : words_rt;
+    const int nth = blockDim.x, tid = threadIdx.x;
+    for (int rb = r_begin; rb < nR; rb += nth) {
+        const int r = rb + tid;
+        const bool valid = r < nR;
+        const uint32_t i = valid ? rlist[r] : 0u;
+        uint32_t a[WORDS > 0 ? WORDS : 1];
+        if (WORDS > 0) {
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) a[w] = valid ? rdesc[(size_t)i * WORDS + w] : 0u;
+        }
+        uint32_t best = PGX_KEY_NONE;
+        for (int cs = c_begin; cs < c_end; cs += 256) {
+            const int cn = (c_end - cs < 256) ? c_end - cs : 256;
+            __syncthreads();
+            for (int t = tid; t < cn; t += nth) {
+                const uint32_t j = clist[cs + t];
+                lds[256 * W + t] = j;
+                for (int w = 0; w < W; w++) lds[t * W + w] = cdesc[(size_t)j * W + w];
+            }
+            __syncthreads();
+            if (valid) {
+                for (int k = 0; k < cn; k++) {
+                    uint32_t d = 0;
+                    if (WORDS > 0) {
+#pragma unroll
+                        for (int w = 0; w < WORDS; w++) d += __popc(a[w] ^ lds[k * WORDS + w]);
+                    } else {
+                        for (int w = 0; w < W; w++) d += __popc(rdesc[(size_t)i * W + w] ^ lds[k * W + w]);
+                    }
+                    const uint32_t key = (d << PGX_IDX_BITS) | lds[256 * W + k];
+                    best = best < key ? best : key;
+                }
+            }
+        }
+        if (valid) {
+            if (use_atomic) atomicMin(&outkey[i], best);
+            else outkey[i] = best;
+        }
+        if (use_atomic) break; // multi-block launch: one row block per workgroup
+    }
+}
+
+constexpr int VALU_CH = 512; // columns per block in the multi-block kernel
+
+template <int WORDS>
+__global__ __launch_bounds__(256) void k_ham_valu(uint32_t *ws, const uint32_t *__restrict__ desc,
+                                                  const int32_t *__restrict__ pairlist, int S, int words, int parity)
+{
+    extern __shared__ uint32_t lds[];
+    const int side = blockIdx.z & 1, m = blockIdx.z >> 1;
+    PairWs p = pair_ws(ws, m, S);
+    const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2];
+    if (n1 <= 0 || n2 <= 0) return;
+    const uint32_t *dA = desc + (size_t)pairlist[2 * m] * S * words;
+    const uint32_t *dB = desc + (size_t)pairlist[2 * m + 1] * S * words;
+    const int nR = side ? n2 : n1, nC = side ? n1 : n2;
+    const int r_begin = blockIdx.x * 256, c_begin = blockIdx.y * VALU_CH;
+    if (r_begin >= nR || c_begin >= nC) return;
+    const int c_end = (c_begin + VALU_CH < nC) ? c_begin + VALU_CH : nC;
+    ham_rows_vs_cols<WORDS>(side ? dB : dA, side ? p.cols[parity] : p.rows[parity], nR, side ? dA : dB,
+                            side ? p.rows[parity] : p.cols[parity], c_begin, c_end, r_begin, words,
+                            side ? p.colkey : p.rowkey, true, lds);
+}
+
+// ---- block-wide helpers ----------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *excl, uint32_t *wsum)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+    for (int w = 0; w < nw; w++) {
+        uint32_t s = wsum[w];
+        if (w < wv) woff += s;
+        total += s;
+    }
+    *excl = woff + incl - v;
+    return total;
+}
+
+// Accept mutual edges of the finished round and stably compact both lists (cur -> nxt).
+// Called by every thread of one workgroup; ends with the new counts in p.cnt and a barrier.
+__device__ void select_compact_wg(PairWs p, int parity, uint32_t *wsum)
+{
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2];
+    const uint32_t *rows = p.rows[parity], *cols = p.cols[parity];
+    uint32_t *nrows = p.rows[parity ^ 1], *ncols = p.cols[parity ^ 1];
+    __syncthreads();
+    // accept: row i's best column j whose best row is i
+    for (int r = tid; r < n1; r += nth) {
+        const uint32_t i = rows[r];
+        const uint32_t rk = p.rowkey[i];
+        const uint32_t j = rk & PGX_IDX_MASK;
+        const uint32_t ck = p.colkey[j];
+        if (rk != PGX_KEY_NONE && ck != PGX_KEY_NONE && (ck & PGX_IDX_MASK) == i) {
+            p.mk2[i] = (int32_t)j;
+            p.md[i] = (int32_t)(rk >> PGX_IDX_BITS);
+            p.rowkey[i] = 0; // retired marker (a live key is never 0 after the reset below)
+        }
+    }
+    __syncthreads();
+    // a column retires iff its best row accepted it (then that row's mk2 points back at it)
+    // stable compaction of rows
+    {
+        const int per = (n1 + nth - 1) / nth;
+        const int b = tid * per, e = (b + per < n1) ? b + per : n1;
+        uint32_t c = 0;
+        for (int r = b; r < e; r++) c += (p.mk2[rows[r]] < 0) ? 1u : 0u;
+        uint32_t ex;
+        const uint32_t tot = block_excl_scan(c, &ex, wsum);
+        uint32_t o = ex;
+        for (int r = b; r < e; r++) {
+            const uint32_t i = rows[r];
+            if (p.mk2[i] < 0) { nrows[o++] = i; p.rowkey[i] = PGX_KEY_NONE; }
+        }
+        __syncthreads();
+        if (tid == 0) { p.cnt[CNT_NACC] += n1 - (int)tot; p.cnt[CNT_N1] = (int)tot; }
+    }
+    {
+        const int per = (n2 + nth - 1) / nth;
+        const int b = tid * per, e = (b + per < n2) ? b + per : n2;
+        uint32_t c = 0;
+        auto col_free = [&](uint32_t j) {
+            const uint32_t ck = p.colkey[j];
+            if (ck == PGX_KEY_NONE) return true;
+            const uint32_t i = ck & PGX_IDX_MASK; // best row of column j this round
+            return !(p.mk2[i] == (int32_t)j);
+        };
+        for (int q = b; q < e; q++) c += col_free(cols[q]) ? 1u : 0u;
+        uint32_t ex;
+        const uint32_t tot = block_excl_scan(c, &ex, wsum);
+        uint32_t o = ex;
+        for (int q = b; q < e; q++) {
+            const uint32_t j = cols[q];
+            if (col_free(j)) ncols[o++] = j;
+        }
+        __syncthreads();
+        // reset the surviving columns' keys only after every thread evaluated col_free
+        for (uint32_t q = tid; q < tot; q += nth) p.colkey[ncols[q]] = PGX_KEY_NONE;
+        if (tid == 0) p.cnt[CNT_N2] = (int)tot;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SEL_NT) void k_match_select(uint32_t *ws, int S, int parity)
+{
+    __shared__ uint32_t wsum[SEL_NT / 64];
+    PairWs p = pair_ws(ws, blockIdx.x, S);
+    if (p.cnt[CNT_N1] <= 0 || p.cnt[CNT_N2] <= 0) return;
+    select_compact_wg(p, parity, wsum);
+}
+
+// bitonic sort of `n2p` (power of two) u32 keys, ascending, by the whole workgroup
+__device__ void bitonic_sort_wg(uint32_t *keys, uint32_t n2p)
+{
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    for (uint32_t k = 2; k <= n2p; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (uint32_t t = tid; t < n2p / 2; t += nth) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const uint32_t a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int WORDS>
+__global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uint32_t *__restrict__ desc,
+                                                         const int32_t *__restrict__ pairlist, int S, int words,
+                                                         int parity, pgx_pair *__restrict__ out, uint32_t lds_keys_cap)
+{
+    extern __shared__ uint32_t lds[];
+    __shared__ uint32_t wsum[SEL_NT / 64];
+    const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    PairWs p = pair_ws(ws, m, S);
+    const uint32_t *dA = desc + (size_t)pairlist[2 * m] * S * words;
+    const uint32_t *dB = desc + (size_t)pairlist[2 * m + 1] * S * words;
+
+    // remaining rounds, entirely inside this workgroup
+    while (true) {
+        const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2];
+        if (n1 <= 0 || n2 <= 0) break; // uniform: cnt is only written behind barriers
+        ham_rows_vs_cols<WORDS>(dA, p.rows[parity], n1, dB, p.cols[parity], 0, n2, 0, words, p.rowkey, false, lds);
+        ham_rows_vs_cols<WORDS>(dB, p.cols[parity], n2, dA, p.rows[parity], 0, n1, 0, words, p.colkey, false, lds);
+        select_compact_wg(p, parity, wsum);
+        parity ^= 1;
+    }
+    __syncthreads();
+
+    // emit: accepted edges sorted by (dist, k1), then the (0,0,int.MaxValue) tail
+    const int n1o = p.cnt[CNT_N1_ORIG];
+    const int nacc = p.cnt[CNT_NACC];
+    pgx_pair *o = out + (size_t)m * S;
+    const uint32_t n2p = (uint32_t)pow2_ge((size_t)(n1o > 1 ? n1o : 1));
+    uint32_t *keys = (n2p <= lds_keys_cap) ? lds : p.skeys;
+    for (uint32_t i = tid; i < n2p; i += nth) {
+        uint32_t k = PGX_KEY_NONE;
+        if ((int)i < n1o && p.mk2[i] >= 0) k = ((uint32_t)p.md[i] << PGX_IDX_BITS) | i;
+        keys[i] = k;
+    }
+    bitonic_sort_wg(keys, n2p);
+    for (int e = tid; e < n1o; e += nth) {
+        pgx_pair r;
+        if (e < nacc) {
+            const uint32_t k = keys[e];
+            const uint32_t i = k & PGX_IDX_MASK;
+            r.k1 = (int32_t)i; r.k2 = p.mk2[i]; r.dist = (int32_t)(k >> PGX_IDX_BITS);
+        } else {
+            r.k1 = 0; r.k2 = 0; r.dist = PGX_DIST_NONE;
+        }
+        o[e] = r;
+    }
+}
+
+} // namespace
+
+#include "k_match_mfma.inc"
+
+size_t pgx_match_ws_bytes(int M, int stride) { return (size_t)M * pair_ws_words(stride) * 4; }
+
+template <int WORDS>
+static void launch_rounds_valu(hipStream_t s, uint32_t *ws, const uint32_t *desc, const int32_t *pairlist,
+                               const MatchPlan &plan, int parity)
+{
+    const int W = WORDS > 0 ? WORDS : plan.words;
+    dim3 grid((plan.max_n + 255) / 256, (plan.max_n + VALU_CH - 1) / VALU_CH, plan.M * 2);
+    const size_t shm = (size_t)256 * (W + 1) * 4;
+    hipLaunchKernelGGL((k_ham_valu<WORDS>), grid, dim3(256), shm, s, ws, desc, pairlist, plan.stride, plan.words, parity);
+}
+
+template <int WORDS>
+static void launch_finish(hipStream_t s, uint32_t *ws, const uint32_t *desc, const int32_t *pairlist,
+                          const MatchPlan &plan, int parity, pgx_pair *out)
+{
+    const int W = WORDS > 0 ? WORDS : plan.words;
+    const size_t ham_words = (size_t)256 * (W + 1);
+    size_t n2p = pow2_ge((size_t)(plan.max_n > 1 ? plan.max_n : 1));
+    size_t key_cap = n2p <= 32768 ? n2p : 0; // <= 128 KiB of LDS for the sort
+    size_t shm_words = ham_words > key_cap ? ham_words : key_cap;
+    static bool attr_set = false; // per template instance
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_finish<WORDS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 8192);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_match_finish<WORDS>), dim3(plan.M), dim3(SEL_NT), shm_words * 4, s, ws, desc, pairlist,
+                       plan.stride, plan.words, parity, out, (uint32_t)key_cap);
+}
+
+void pgx_launch_match(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_counts,
+                      const int32_t *d_pairlist, const MatchPlan &plan, void *wsv, pgx_pair *d_out, int *status)
+{
+    if (plan.M <= 0) return;
+    uint32_t *ws = reinterpret_cast<uint32_t *>(wsv);
+    {
+        ProfScope ps(ctx, "match_init");
+        hipLaunchKernelGGL(k_match_init, dim3((plan.stride + 255) / 256 > 64 ? 64 : (plan.stride + 255) / 256, plan.M),
+                           dim3(256), 0, s, ws, d_counts, d_pairlist, plan.stride, status);
+    }
+    int parity = 0;
+    const bool mfma_ok = (plan.words == 8) && pgx_mfma_enabled();
+    for (int r = 0; r < plan.rounds_mfma; r++) {
+        {
+            ProfScope ps(ctx, "ham_argmin");
+            if (mfma_ok) pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan, parity);
+            else if (plan.words == 8) launch_rounds_valu<8>(s, ws, d_desc, d_pairlist, plan, parity);
+            else launch_rounds_valu<0>(s, ws, d_desc, d_pairlist, plan, parity);
+        }
+        {
+            ProfScope ps(ctx, "match_select");
+            hipLaunchKernelGGL(k_match_select, dim3(plan.M), dim3(SEL_NT), 0, s, ws, plan.stride, parity);
+        }
+        parity ^= 1;
+    }
+    {
+        ProfScope ps(ctx, "match_finish");
+        if (plan.words == 8) launch_finish<8>(s, ws, d_desc, d_pairlist, plan, parity, d_out);
+        else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, parity, d_out);
+    }
+}

@@ -1,0 +1,503 @@
+// pgx_api.hip -- the C ABI of libpgx.so (see include/pgx.h): context, configuration,
+// host-buffer entry points (copy in -> kernels -> copy out) and the device-resident batched
+// entry points.  All compute is in the k_*.hip kernels; there is no CPU fallback anywhere:
+// every entry point needs a working gfx950 device and fails with PGX_E_HIP without one.
+#include "pgx_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <new>
+#include <cstring>
+
+#define PGX_VERSION_STR "pgx 0.1 (gfx950)"
+
+namespace {
+
+int fail(pgx_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                           \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail((c), PGX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Lock {
+    std::lock_guard<std::mutex> g;
+    explicit Lock(pgx_ctx *c) : g(c->mu) { (void)hipSetDevice(c->device); }
+};
+
+int decode_status(pgx_ctx *c, int bits)
+{
+    if (bits & PGX_ST_OOB_SOURCE)
+        return fail(c, PGX_E_OOB_SOURCE, "dewarp map points outside the source image (IndexOutOfRangeException)");
+    if (bits & PGX_ST_EMPTY_SET)
+        return fail(c, PGX_E_EMPTY_SET, "keypoints2 is empty while keypoints1 is not (ArgumentOutOfRangeException)");
+    if (bits & PGX_ST_RAW_CAP)
+        return fail(c, PGX_E_CAPACITY, "raw FAST hits exceed max_raw_per_frame (pgx_set_capacity)");
+    if (bits & PGX_ST_KP_CAP) return fail(c, PGX_E_CAPACITY, "NMS survivors exceed the output capacity");
+    return PGX_OK;
+}
+
+// wait for the stream, read and clear the sticky status word
+int sync_status(pgx_ctx *c)
+{
+    HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return decode_status(c, c->h_status[0]);
+}
+
+// detect chain on device-resident frames (enqueue only)
+int enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_keypoint *d_kp, uint32_t *d_desc,
+                   int32_t *d_counts, int32_t *d_nraw, int cap)
+{
+    if (!c->params_set) return fail(c, PGX_E_NOT_CONFIGURED, "pgx_set_detect_params not called");
+    if (!c->pairs_set) return fail(c, PGX_E_NOT_CONFIGURED, "pgx_set_brief_pairs not called");
+    if (c->map_set && (c->mapW != W || c->mapH != H))
+        return fail(c, PGX_E_DIM_MISMATCH, "image %dx%d vs dewarp map %dx%d (ArgumentException)", W, H, c->mapW, c->mapH);
+    if (F <= 0) return PGX_OK;
+    const size_t npix = (size_t)W * H;
+    const size_t nseg = pgx_fast_seg_count(W, H);
+    const int raw_cap = c->raw_cap;
+    HIPCHK(c, c->ws_gray.ensure((size_t)F * npix * 4));
+    HIPCHK(c, c->ws_seg.ensure((size_t)F * nseg * 32));
+    HIPCHK(c, c->ws_segoff.ensure((size_t)F * nseg * 4));
+    HIPCHK(c, c->ws_rawxy.ensure((size_t)F * raw_cap * 4));
+    HIPCHK(c, c->ws_rawscore.ensure((size_t)F * raw_cap * 4));
+    const size_t nms_stride = pgx_nms_ws_bytes(W, H, c->radius, raw_cap);
+    HIPCHK(c, c->ws_nms.ensure((size_t)F * nms_stride));
+    HIPCHK(c, c->ws_order.ensure((size_t)F * cap * 4));
+    HIPCHK(c, c->ws_nkept.ensure((size_t)F * 4));
+
+    float *gray = c->ws_gray.as<float>();
+    {
+        ProfScope ps(c, "dewarp_gray");
+        pgx_launch_dewarp_gray(c->stream, d_rgba, c->map_set ? c->d_map.as<int32_t>() : nullptr, F, W, H, gray,
+                               nullptr, c->d_status);
+    }
+    {
+        ProfScope ps(c, "fast");
+        pgx_launch_fast(c->stream, gray, F, W, H, c->threshold, c->ws_seg.as<unsigned long long>(),
+                        c->ws_segoff.as<uint32_t>(), d_nraw, c->ws_rawxy.as<uint32_t>(),
+                        c->ws_rawscore.as<int32_t>(), raw_cap, c->d_status);
+    }
+    {
+        ProfScope ps(c, "nms");
+        pgx_launch_nms(c->stream, c->ws_rawxy.as<uint32_t>(), c->ws_rawscore.as<int32_t>(), d_nraw, F, raw_cap, W, H,
+                       c->radius, c->ws_nms.p, nms_stride, c->ws_order.as<uint32_t>(), c->ws_nkept.as<int32_t>(),
+                       cap, c->d_status);
+    }
+    {
+        ProfScope ps(c, "brief");
+        pgx_launch_brief(c->stream, gray, F, W, H, c->ws_rawxy.as<uint32_t>(), c->ws_rawscore.as<int32_t>(), raw_cap,
+                         c->ws_order.as<uint32_t>(), c->ws_nkept.as<int32_t>(), cap, c->d_pairs.as<int32_t>(), c->P,
+                         d_kp, d_desc, d_counts);
+    }
+    HIPCHK(c, hipGetLastError());
+    return PGX_OK;
+}
+
+int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, int stride, int words,
+                  const int32_t *d_pairlist, int M, int max_n, pgx_pair *d_out)
+{
+    if (M <= 0) return PGX_OK;
+    if (stride <= 0 || stride > (1 << PGX_IDX_BITS)) return fail(c, PGX_E_BADARG, "stride must be in [1, 2^20]");
+    if (words <= 0 || words > 127) return fail(c, PGX_E_BADARG, "words must be in [1, 127] (P <= 4064)");
+    HIPCHK(c, c->ws_match.ensure(pgx_match_ws_bytes(M, stride)));
+    MatchPlan plan;
+    plan.M = M; plan.stride = stride; plan.words = words;
+    plan.max_n = max_n > stride ? stride : (max_n < 1 ? 1 : max_n);
+    // rounds on the all-CU distance kernel before the per-pair workgroup finishes the tail
+    plan.rounds_mfma = plan.max_n <= 256 ? 0 : (plan.max_n <= 1024 ? 2 : 4);
+    pgx_launch_match(c, c->stream, d_desc, d_counts, d_pairlist, plan, c->ws_match.p, d_out, c->d_status);
+    c->last_rounds_mfma = plan.rounds_mfma;
+    HIPCHK(c, hipGetLastError());
+    return PGX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *pgx_version(void) { return PGX_VERSION_STR; }
+
+int pgx_ctx_create(int device, pgx_ctx **out)
+{
+    if (!out) return PGX_E_BADARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PGX_E_HIP;
+    if (hipSetDevice(device) != hipSuccess) return PGX_E_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return PGX_E_HIP;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "pgx: device %d is %s; this library is built for gfx950 only\n", device, prop.gcnArchName);
+        return PGX_E_HIP;
+    }
+    pgx_ctx *c = new (std::nothrow) pgx_ctx();
+    if (!c) return PGX_E_HIP;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->d_status), 64) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_status), 64, hipHostMallocDefault) != hipSuccess ||
+        hipMemset(c->d_status, 0, 64) != hipSuccess) {
+        pgx_ctx_destroy(c);
+        return PGX_E_HIP;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return PGX_OK;
+}
+
+void pgx_ctx_destroy(pgx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &kv : c->prof)
+        for (auto &ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    DevBuf *bufs[] = {&c->d_pairs, &c->d_map, &c->ws_gray, &c->ws_seg, &c->ws_segoff, &c->ws_nraw, &c->ws_rawxy,
+                      &c->ws_rawscore, &c->ws_nms, &c->ws_order, &c->ws_nkept, &c->st_a, &c->st_b, &c->st_c,
+                      &c->st_d, &c->st_e, &c->st_f, &c->ws_match};
+    for (DevBuf *b : bufs) b->release();
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char *pgx_last_error(pgx_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int pgx_set_stream(pgx_ctx *c, void *hip_stream)
+{
+    if (!c) return PGX_E_BADARG;
+    Lock l(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return PGX_OK;
+}
+
+int pgx_check_status(pgx_ctx *c)
+{
+    if (!c) return PGX_E_BADARG;
+    Lock l(c);
+    return sync_status(c);
+}
+
+int pgx_set_dewarp_map(pgx_ctx *c, const int32_t *uv, int W, int H)
+{
+    if (!c) return PGX_E_BADARG;
+    Lock l(c);
+    if (!uv) { c->map_set = false; c->mapW = c->mapH = 0; return PGX_OK; }
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return fail(c, PGX_E_BADARG, "map dimensions must fit ushort");
+    const size_t bytes = (size_t)W * H * 8;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, c->d_map.ensure(bytes + 32));
+    HIPCHK(c, hipMemcpy(c->d_map.p, uv, bytes, hipMemcpyHostToDevice));
+    c->mapW = W; c->mapH = H; c->map_set = true;
+    return PGX_OK;
+}
+
+int pgx_set_brief_pairs(pgx_ctx *c, const int32_t *pairs, int P)
+{
+    if (!c) return PGX_E_BADARG;
+    Lock l(c);
+    if (!pairs || P <= 0 || P > 4064) return fail(c, PGX_E_BADARG, "P must be in [1, 4064]");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, c->d_pairs.ensure((size_t)P * 16));
+    HIPCHK(c, hipMemcpy(c->d_pairs.p, pairs, (size_t)P * 16, hipMemcpyHostToDevice));
+    c->P = P; c->words = (P + 31) / 32; c->pairs_set = true;
+    return PGX_OK;
+}
+
+int pgx_set_detect_params(pgx_ctx *c, float threshold, int suppression_radius)
+{
+    if (!c) return PGX_E_BADARG;
+    Lock l(c);
+    c->threshold = threshold; c->radius = suppression_radius; c->params_set = true;
+    return PGX_OK;
+}
+
+int pgx_set_capacity(pgx_ctx *c, int max_raw, int max_kp)
+{
+    if (!c) return PGX_E_BADARG;
+    Lock l(c);
+    if (max_raw <= 0 || max_kp <= 0 || max_kp > (1 << PGX_IDX_BITS)) return fail(c, PGX_E_BADARG, "bad capacity");
+    c->raw_cap = max_raw; c->kp_cap = max_kp;
+    return PGX_OK;
+}
+
+// ---- stage-granular host entry points ---------------------------------------------------
+
+int pgx_dewarp(pgx_ctx *c, const uint16_t *rgba, int W, int H, uint16_t *out)
+{
+    if (!c || !rgba || !out) return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    if (!c->map_set) return fail(c, PGX_E_NOT_CONFIGURED, "pgx_set_dewarp_map not called");
+    if (W != c->mapW || H != c->mapH)   // DeWarp.cs:22-23
+        return fail(c, PGX_E_DIM_MISMATCH, "image %dx%d vs dewarp map %dx%d (ArgumentException)", W, H, c->mapW, c->mapH);
+    const size_t bytes = (size_t)W * H * 8;
+    HIPCHK(c, c->st_a.ensure(bytes + 32));
+    HIPCHK(c, c->st_b.ensure(bytes + 32));
+    HIPCHK(c, hipMemcpyAsync(c->st_a.p, rgba, bytes, hipMemcpyHostToDevice, c->stream));
+    pgx_launch_dewarp_gray(c->stream, c->st_a.as<uint16_t>(), c->d_map.as<int32_t>(), 1, W, H, nullptr,
+                           c->st_b.as<uint16_t>(), c->d_status);
+    HIPCHK(c, hipMemcpyAsync(out, c->st_b.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    return sync_status(c);
+}
+
+int pgx_gray(pgx_ctx *c, const uint16_t *rgba, int W, int H, float *out)
+{
+    if (!c || !rgba || !out) return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return fail(c, PGX_E_BADARG, "dimensions must fit ushort");
+    const size_t npix = (size_t)W * H;
+    HIPCHK(c, c->st_a.ensure(npix * 8 + 32));
+    HIPCHK(c, c->st_b.ensure(npix * 4 + 32));
+    HIPCHK(c, hipMemcpyAsync(c->st_a.p, rgba, npix * 8, hipMemcpyHostToDevice, c->stream));
+    pgx_launch_dewarp_gray(c->stream, c->st_a.as<uint16_t>(), nullptr, 1, W, H, c->st_b.as<float>(), nullptr,
+                           c->d_status);
+    HIPCHK(c, hipMemcpyAsync(out, c->st_b.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    return sync_status(c);
+}
+
+int pgx_fast(pgx_ctx *c, const float *gray, int W, int H, pgx_keypoint *out, int capacity, int *n_out)
+{
+    if (!c || !gray || !n_out || (capacity > 0 && !out) || capacity < 0)
+        return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    if (!c->params_set) return fail(c, PGX_E_NOT_CONFIGURED, "pgx_set_detect_params not called");
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return fail(c, PGX_E_BADARG, "dimensions must fit ushort");
+    const size_t npix = (size_t)W * H, nseg = pgx_fast_seg_count(W, H);
+    const int cap = capacity > 0 ? capacity : 1;
+    HIPCHK(c, c->st_a.ensure(npix * 4 + 32));
+    HIPCHK(c, c->ws_seg.ensure(nseg * 32));
+    HIPCHK(c, c->ws_segoff.ensure(nseg * 4));
+    HIPCHK(c, c->ws_nraw.ensure(64));
+    HIPCHK(c, c->st_b.ensure((size_t)cap * 4));
+    HIPCHK(c, c->st_c.ensure((size_t)cap * 4));
+    HIPCHK(c, hipMemcpyAsync(c->st_a.p, gray, npix * 4, hipMemcpyHostToDevice, c->stream));
+    pgx_launch_fast(c->stream, c->st_a.as<float>(), 1, W, H, c->threshold, c->ws_seg.as<unsigned long long>(),
+                    c->ws_segoff.as<uint32_t>(), c->ws_nraw.as<int32_t>(), c->st_b.as<uint32_t>(),
+                    c->st_c.as<int32_t>(), cap, c->d_status);
+    int n = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, c->ws_nraw.p, 4, hipMemcpyDeviceToHost, c->stream));
+    int rc = sync_status(c);
+    *n_out = n;
+    const int nw = n < capacity ? n : capacity;
+    if (nw > 0) {
+        std::vector<uint32_t> xy(nw);
+        std::vector<int32_t> sc(nw);
+        HIPCHK(c, hipMemcpy(xy.data(), c->st_b.p, (size_t)nw * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(sc.data(), c->st_c.p, (size_t)nw * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < nw; i++) {
+            out[i].x = (int32_t)(xy[i] & 0xFFFFu);
+            out[i].y = (int32_t)(xy[i] >> 16);
+            out[i].fast_score = sc[i];
+            out[i].value = gray[(size_t)out[i].y * W + out[i].x]; // Keypoint.cs:26 (a copy of the caller's pixel)
+        }
+    }
+    if (rc == PGX_OK && n > capacity) return fail(c, PGX_E_CAPACITY, "%d hits, capacity %d", n, capacity);
+    return rc;
+}
+
+int pgx_brief(pgx_ctx *c, const float *gray, int W, int H, const pgx_keypoint *kps, int n, uint32_t *desc_out)
+{
+    if (!c || !gray || n < 0 || (n > 0 && (!kps || !desc_out)))
+        return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    if (!c->pairs_set) return fail(c, PGX_E_NOT_CONFIGURED, "pgx_set_brief_pairs not called");
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return fail(c, PGX_E_BADARG, "dimensions must fit ushort");
+    if (n == 0) return PGX_OK;
+    const size_t npix = (size_t)W * H;
+    HIPCHK(c, c->st_a.ensure(npix * 4 + 32));
+    HIPCHK(c, c->st_b.ensure((size_t)n * sizeof(pgx_keypoint)));
+    HIPCHK(c, c->st_c.ensure((size_t)n * c->words * 4));
+    HIPCHK(c, hipMemcpyAsync(c->st_a.p, gray, npix * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->st_b.p, kps, (size_t)n * sizeof(pgx_keypoint), hipMemcpyHostToDevice, c->stream));
+    pgx_launch_brief_list(c->stream, c->st_a.as<float>(), W, H, c->st_b.as<pgx_keypoint>(), n,
+                          c->d_pairs.as<int32_t>(), c->P, c->st_c.as<uint32_t>());
+    HIPCHK(c, hipMemcpyAsync(desc_out, c->st_c.p, (size_t)n * c->words * 4, hipMemcpyDeviceToHost, c->stream));
+    return sync_status(c);
+}
+
+int pgx_nms(pgx_ctx *c, const pgx_keypoint *kps, int n, int W, int H, int32_t *order_out, int *n_out)
+{
+    if (!c || !n_out || n < 0 || (n > 0 && (!kps || !order_out)))
+        return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    if (!c->params_set) return fail(c, PGX_E_NOT_CONFIGURED, "pgx_set_detect_params not called");
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return fail(c, PGX_E_BADARG, "dimensions must fit ushort");
+    *n_out = 0;
+    if (n == 0) return PGX_OK;
+    std::vector<uint32_t> xy(n);
+    std::vector<int32_t> sc(n);
+    for (int i = 0; i < n; i++) {
+        if (kps[i].x < 0 || kps[i].x >= W || kps[i].y < 0 || kps[i].y >= H)
+            return fail(c, PGX_E_BADARG, "keypoint %d (%d,%d) outside %dx%d", i, kps[i].x, kps[i].y, W, H);
+        xy[i] = ((uint32_t)kps[i].y << 16) | (uint32_t)kps[i].x;
+        sc[i] = kps[i].fast_score;
+    }
+    const size_t wsb = pgx_nms_ws_bytes(W, H, c->radius, n);
+    HIPCHK(c, c->st_a.ensure((size_t)n * 4));
+    HIPCHK(c, c->st_b.ensure((size_t)n * 4));
+    HIPCHK(c, c->st_c.ensure((size_t)n * 4));
+    HIPCHK(c, c->st_d.ensure(64));
+    HIPCHK(c, c->ws_nms.ensure(wsb));
+    HIPCHK(c, hipMemcpyAsync(c->st_a.p, xy.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->st_b.p, sc.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->st_d.p, &n, 4, hipMemcpyHostToDevice, c->stream));
+    pgx_launch_nms(c->stream, c->st_a.as<uint32_t>(), c->st_b.as<int32_t>(), c->st_d.as<int32_t>(), 1, n, W, H,
+                   c->radius, c->ws_nms.p, wsb, c->st_c.as<uint32_t>(), c->st_d.as<int32_t>() + 1, n, c->d_status);
+    int nk = 0;
+    HIPCHK(c, hipMemcpyAsync(&nk, c->st_d.as<int32_t>() + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    int rc = sync_status(c);
+    if (rc != PGX_OK) return rc;
+    *n_out = nk;
+    if (nk > 0) HIPCHK(c, hipMemcpy(order_out, c->st_c.p, (size_t)nk * 4, hipMemcpyDeviceToHost));
+    return PGX_OK;
+}
+
+int pgx_match(pgx_ctx *c, const uint32_t *desc1, int n1, const uint32_t *desc2, int n2, int words, pgx_pair *out)
+{
+    if (!c || n1 < 0 || n2 < 0 || (n1 > 0 && (!desc1 || !out)) || (n2 > 0 && !desc2))
+        return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    if (n1 == 0) return PGX_OK;                                  // KeypointMatching.cs:38: loop never runs
+    if (n2 == 0) return fail(c, PGX_E_EMPTY_SET, "keypoints2 is empty (ArgumentOutOfRangeException)"); // :61
+    if (words <= 0 || words > 127) return fail(c, PGX_E_BADARG, "words must be in [1, 127]");
+    const int S = n1 > n2 ? n1 : n2;
+    if (S > (1 << PGX_IDX_BITS)) return fail(c, PGX_E_BADARG, "more than 2^20 keypoints");
+    // two "frames" of S slots
+    HIPCHK(c, c->st_a.ensure((size_t)2 * S * words * 4));
+    HIPCHK(c, c->st_b.ensure(64));
+    HIPCHK(c, c->st_c.ensure((size_t)S * sizeof(pgx_pair)));
+    const int32_t meta[4] = {n1, n2, 0, 1}; // counts[2], pairlist[1][2]
+    HIPCHK(c, hipMemcpyAsync(c->st_a.p, desc1, (size_t)n1 * words * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->st_a.as<uint32_t>() + (size_t)S * words, desc2, (size_t)n2 * words * 4,
+                             hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->st_b.p, meta, sizeof meta, hipMemcpyHostToDevice, c->stream));
+    int rc = enqueue_match(c, c->st_a.as<uint32_t>(), c->st_b.as<int32_t>(), S, words, c->st_b.as<int32_t>() + 2, 1,
+                           S, c->st_c.as<pgx_pair>());
+    if (rc != PGX_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->st_c.p, (size_t)n1 * sizeof(pgx_pair), hipMemcpyDeviceToHost, c->stream));
+    return sync_status(c);
+}
+
+int pgx_detect(pgx_ctx *c, const uint16_t *rgba, int W, int H, pgx_keypoint *kp_out, uint32_t *desc_out,
+               int capacity, int *n_out, int *n_raw)
+{
+    if (!c || !rgba || !kp_out || !desc_out || !n_out || capacity <= 0)
+        return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return fail(c, PGX_E_BADARG, "dimensions must fit ushort");
+    const size_t npix = (size_t)W * H;
+    HIPCHK(c, c->st_e.ensure(npix * 8 + 32));
+    HIPCHK(c, c->st_f.ensure((size_t)capacity * (sizeof(pgx_keypoint) + (size_t)(c->words ? c->words : 1) * 4) + 64));
+    pgx_keypoint *d_kp = c->st_f.as<pgx_keypoint>();
+    uint32_t *d_desc = reinterpret_cast<uint32_t *>(d_kp + capacity);
+    int32_t *d_cnt = reinterpret_cast<int32_t *>(d_desc + (size_t)capacity * (c->words ? c->words : 1));
+    HIPCHK(c, hipMemcpyAsync(c->st_e.p, rgba, npix * 8, hipMemcpyHostToDevice, c->stream));
+    int rc = enqueue_detect(c, c->st_e.as<uint16_t>(), 1, W, H, d_kp, d_desc, d_cnt, d_cnt + 1, capacity);
+    if (rc != PGX_OK) return rc;
+    int cnt[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    rc = sync_status(c);
+    *n_out = cnt[0];
+    if (n_raw) *n_raw = cnt[1];
+    if (cnt[0] > 0) {
+        HIPCHK(c, hipMemcpy(kp_out, d_kp, (size_t)cnt[0] * sizeof(pgx_keypoint), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(desc_out, d_desc, (size_t)cnt[0] * c->words * 4, hipMemcpyDeviceToHost));
+    }
+    return rc;
+}
+
+// ---- device-resident batched entry points -------------------------------------------------
+
+int pgx_detect_batch_dev(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_keypoint *d_kp,
+                         uint32_t *d_desc, int32_t *d_counts, int32_t *d_nraw, int capacity)
+{
+    if (!c || !d_rgba || !d_kp || !d_desc || !d_counts || !d_nraw || capacity <= 0 || F < 0)
+        return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return fail(c, PGX_E_BADARG, "dimensions must fit ushort");
+    return enqueue_detect(c, d_rgba, F, W, H, d_kp, d_desc, d_counts, d_nraw, capacity);
+}
+
+int pgx_match_batch_dev(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, int stride, int words,
+                        const int32_t *d_pairlist, int M, pgx_pair *d_out)
+{
+    if (!c || !d_desc || !d_counts || !d_pairlist || !d_out || M < 0)
+        return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    return enqueue_match(c, d_desc, d_counts, stride, words, d_pairlist, M, stride, d_out);
+}
+
+// ---- measurement hooks ---------------------------------------------------------------------
+
+int pgx_profile_enable(pgx_ctx *c, int on)
+{
+    if (!c) return PGX_E_BADARG;
+    Lock l(c);
+    c->prof_on = on != 0;
+    return PGX_OK;
+}
+
+static void prof_drain(pgx_ctx *c)
+{
+    for (auto &kv : c->prof) {
+        for (auto &ev : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+                kv.second.total_ms += ms;
+                kv.second.launches += 1;
+            }
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+int pgx_profile_get(pgx_ctx *c, const char *name, int *launches, double *total_ms)
+{
+    if (!c || !name) return PGX_E_BADARG;
+    Lock l(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_drain(c);
+    auto it = c->prof.find(name);
+    if (launches) *launches = it == c->prof.end() ? 0 : it->second.launches;
+    if (total_ms) *total_ms = it == c->prof.end() ? 0.0 : it->second.total_ms;
+    return PGX_OK;
+}
+
+int pgx_profile_reset(pgx_ctx *c)
+{
+    if (!c) return PGX_E_BADARG;
+    Lock l(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_drain(c);
+    c->prof.clear();
+    return PGX_OK;
+}
+
+int pgx_match_stats(pgx_ctx *c, int *rounds_mfma, int64_t *evaluations)
+{
+    if (!c) return PGX_E_BADARG;
+    Lock l(c);
+    if (rounds_mfma) *rounds_mfma = c->last_rounds_mfma;
+    if (evaluations) *evaluations = c->last_evals;
+    return PGX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,149 @@
+// pgx_internal.h -- shared between the HIP translation units of libpgx.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/pgx.h"
+
+// status bits set by kernels (device word 0), decoded by pgx_check_status
+#define PGX_ST_OOB_SOURCE 1u
+#define PGX_ST_RAW_CAP    2u
+#define PGX_ST_KP_CAP     4u
+#define PGX_ST_EMPTY_SET  8u
+
+// key = (distance << PGX_IDX_BITS) | index ; limits: index < 2^20, distance < 2^12
+#define PGX_IDX_BITS 20
+#define PGX_IDX_MASK ((1u << PGX_IDX_BITS) - 1u)
+#define PGX_KEY_NONE 0xFFFFFFFFu
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct ProfEntry {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    int launches = 0;
+    double total_ms = 0.0;
+};
+
+struct pgx_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+
+    // configuration
+    float threshold = 0.f;
+    int radius = 0;
+    bool params_set = false;
+    int P = 0, words = 0;
+    bool pairs_set = false;
+    DevBuf d_pairs;
+    int mapW = 0, mapH = 0;
+    bool map_set = false;
+    DevBuf d_map;
+    int raw_cap = 1 << 17;
+    int kp_cap = 8192;
+
+    // status words: [0] sticky error bits
+    int *d_status = nullptr;
+    int *h_status = nullptr; // pinned
+
+    // detect workspaces
+    DevBuf ws_gray, ws_seg, ws_segoff, ws_nraw, ws_rawxy, ws_rawscore, ws_nms, ws_order, ws_nkept;
+    // host-API staging
+    DevBuf st_a, st_b, st_c, st_d, st_e, st_f;
+    // match workspaces
+    DevBuf ws_match;
+
+    // profiling
+    bool prof_on = false;
+    std::map<std::string, ProfEntry> prof;
+
+    // last match stats
+    int last_rounds_mfma = 0;
+    long long last_evals = 0;
+};
+
+// RAII event bracket used by the launchers' callers
+struct ProfScope {
+    pgx_ctx *c;
+    ProfEntry *e = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(pgx_ctx *ctx, const char *name) : c(ctx)
+    {
+        if (!c->prof_on) return;
+        e = &c->prof[name];
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { e = nullptr; return; }
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~ProfScope()
+    {
+        if (!e) return;
+        (void)hipEventRecord(b, c->stream);
+        e->pending.emplace_back(a, b);
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// kernel launchers (each .hip file owns its kernels)
+// ---------------------------------------------------------------------------------------
+
+// k_image.hip
+void pgx_launch_dewarp_gray(hipStream_t s, const uint16_t *rgba, const int32_t *map_uv, int F, int W, int H,
+                            float *gray, uint16_t *dewarped, int *status);
+
+// k_fast.hip
+size_t pgx_fast_seg_count(int W, int H);   // segments per frame
+void pgx_launch_fast(hipStream_t s, const float *gray, int F, int W, int H, float T,
+                     unsigned long long *seg /*[F][nseg][4]*/, uint32_t *segoff /*[F][nseg]*/,
+                     int32_t *n_raw /*[F]*/, uint32_t *raw_xy /*[F][raw_cap]*/,
+                     int32_t *raw_score /*[F][raw_cap]*/, int raw_cap, int *status);
+
+// k_nms.hip
+size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap);  // per frame
+void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw,
+                    int F, int n_cap, int W, int H, int radius, void *ws, size_t ws_stride,
+                    uint32_t *order /*[F][kp_cap]*/, int32_t *n_kept /*[F]*/, int kp_cap, int *status);
+
+// k_brief.hip
+void pgx_launch_brief(hipStream_t s, const float *gray, int F, int W, int H,
+                      const uint32_t *raw_xy, const int32_t *raw_score, int raw_cap,
+                      const uint32_t *order, const int32_t *n_kept, int kp_cap,
+                      const int32_t *pairs, int P,
+                      pgx_keypoint *kp_out, uint32_t *desc_out, int32_t *counts_out);
+// descriptors for an explicit keypoint list (stage API)
+void pgx_launch_brief_list(hipStream_t s, const float *gray, int W, int H, const pgx_keypoint *kps, int n,
+                           const int32_t *pairs, int P, uint32_t *desc_out);
+
+// k_match.hip
+struct MatchPlan {
+    int M;        // image pairs
+    int stride;   // descriptor slots per frame
+    int words;
+    int max_n;    // upper bound of any count (<= stride)
+    int rounds_mfma;
+};
+size_t pgx_match_ws_bytes(int M, int stride);
+void pgx_launch_match(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_counts,
+                      const int32_t *d_pairlist, const MatchPlan &plan, void *ws, pgx_pair *d_out, int *status);
