@@ -113,9 +113,12 @@ int pgx_detect_batch_dev(pgx_ctx *ctx, const uint16_t *d_rgba64, int F, int W, i
 /* M image pairs: d_pairlist [M][2] = (frame_a, frame_b) indexes descriptor sets
  * d_desc [F][stride][words] with d_counts [F].  d_out [M][stride]: the first counts[a] entries of
  * row m are the reference's match list for (a, b).  Pairs with counts[b] == 0 < counts[a] raise
- * PGX_E_EMPTY_SET in pgx_check_status and leave their row filled with (0,0,PGX_DIST_NONE). */
+ * PGX_E_EMPTY_SET in pgx_check_status and leave their row filled with (0,0,PGX_DIST_NONE).
+ * max_count = an upper bound of every d_counts entry used (<= stride; pass stride if unknown):
+ * it only sizes the launch grids, counts above it are clamped to it. */
 int pgx_match_batch_dev(pgx_ctx *ctx, const uint32_t *d_desc, const int32_t *d_counts,
-                        int stride, int words, const int32_t *d_pairlist, int M, pgx_pair *d_out);
+                        int stride, int words, const int32_t *d_pairlist, int M, int max_count,
+                        pgx_pair *d_out);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------- */
 /* When on, the named hot kernels are bracketed by HIP events on the launch stream. */
@@ -124,9 +127,10 @@ int pgx_profile_enable(pgx_ctx *ctx, int on);
  * launches and total milliseconds.  Synchronises the stream. */
 int pgx_profile_get(pgx_ctx *ctx, const char *name, int *launches, double *total_ms);
 int pgx_profile_reset(pgx_ctx *ctx);
-/* Counters of the last pgx_match* call: greedy rounds run on the MFMA path and the number of
- * descriptor-pair distance evaluations issued (sum over rounds of n1*n2). */
-int pgx_match_stats(pgx_ctx *ctx, int *rounds_mfma, int64_t *evaluations);
+/* Counters of the last pgx_match* call: rounds run on the all-CU distance kernel, and the
+ * descriptor-pair distance evaluations those launches issued (sum over rounds and image pairs of
+ * n1*n2; evaluations_round0 = the first launch alone = sum of N1*N2).  Synchronises the stream. */
+int pgx_match_stats(pgx_ctx *ctx, int *rounds_wide, int64_t *evaluations, int64_t *evaluations_round0);
 
 /* ---- host-side helpers (no GPU work) -------------------------------------------------- */
 /* Utils.NextGaussianPair (Utils.cs:14-38) on a seeded splitmix64 stream; out [P][4]. */

@@ -171,9 +171,15 @@ class Engine:
         self._chk(self._L.pgx_detect_batch_dev(self._h, _dptr(d_rgba64), int(F), int(W), int(H), _dptr(d_kp),
                                                _dptr(d_desc), _dptr(d_counts), _dptr(d_nraw), int(capacity)))
 
-    def match_batch_dev(self, d_desc, d_counts, stride, words, d_pairlist, M, d_out):
+    def match_batch_dev(self, d_desc, d_counts, stride, words, d_pairlist, M, d_out, max_count=None):
         self._chk(self._L.pgx_match_batch_dev(self._h, _dptr(d_desc), _dptr(d_counts), int(stride), int(words),
-                                              _dptr(d_pairlist), int(M), _dptr(d_out)))
+                                              _dptr(d_pairlist), int(M),
+                                              int(stride if max_count is None else max_count), _dptr(d_out)))
+
+    def match_stats(self):
+        r, ev, ev0 = C.c_int(0), C.c_int64(0), C.c_int64(0)
+        self._chk(self._L.pgx_match_stats(self._h, C.byref(r), C.byref(ev), C.byref(ev0)))
+        return r.value, ev.value, ev0.value
 
     # -- measurement ------------------------------------------------------------------------
     def profile_enable(self, on=True):

@@ -28,7 +28,7 @@
 namespace {
 
 constexpr int SEL_NT = 1024;
-constexpr int CNT_N1 = 0, CNT_N2 = 1, CNT_NACC = 2, CNT_N1_ORIG = 3, CNT_N2_ORIG = 4, CNT_WORDS = 8;
+constexpr int CNT_N1 = 0, CNT_N2 = 1, CNT_NACC = 2, CNT_N1_ORIG = 3, CNT_N2_ORIG = 4, CNT_PARITY = 5, CNT_WORDS = 8;
 
 struct PairWs {
     uint32_t *rowkey, *colkey, *rows[2], *cols[2];
@@ -56,13 +56,14 @@ __device__ __forceinline__ PairWs pair_ws(uint32_t *ws, int m, int S)
 }
 
 __global__ __launch_bounds__(256) void k_match_init(uint32_t *ws, const int32_t *__restrict__ counts,
-                                                    const int32_t *__restrict__ pairlist, int S, int *status)
+                                                    const int32_t *__restrict__ pairlist, int S, int max_n,
+                                                    int *status)
 {
     const int m = blockIdx.y;
     PairWs p = pair_ws(ws, m, S);
     int n1 = counts[pairlist[2 * m]], n2 = counts[pairlist[2 * m + 1]];
-    n1 = n1 < 0 ? 0 : (n1 > S ? S : n1);
-    n2 = n2 < 0 ? 0 : (n2 > S ? S : n2);
+    n1 = n1 < 0 ? 0 : (n1 > max_n ? max_n : n1); // lists are truncated to their first max_count entries
+    n2 = n2 < 0 ? 0 : (n2 > max_n ? max_n : n2);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
         p.rowkey[i] = PGX_KEY_NONE;
         p.colkey[i] = PGX_KEY_NONE;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void k_match_init(uint32_t *ws, const int32_t 
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         p.cnt[CNT_N1] = n1; p.cnt[CNT_N2] = n2; p.cnt[CNT_NACC] = 0;
-        p.cnt[CNT_N1_ORIG] = n1; p.cnt[CNT_N2_ORIG] = n2;
+        p.cnt[CNT_N1_ORIG] = n1; p.cnt[CNT_N2_ORIG] = n2; p.cnt[CNT_PARITY] = 0;
         if (n1 > 0 && n2 == 0) atomicOr(status, (int)PGX_ST_EMPTY_SET); // KeypointMatching.cs:61
     }
 }
@@ -135,13 +136,14 @@ constexpr int VALU_CH = 512; // columns per block in the multi-block kernel
 
 template <int WORDS>
 __global__ __launch_bounds__(256) void k_ham_valu(uint32_t *ws, const uint32_t *__restrict__ desc,
-                                                  const int32_t *__restrict__ pairlist, int S, int words, int parity)
+                                                  const int32_t *__restrict__ pairlist, int S, int words)
 {
     extern __shared__ uint32_t lds[];
     const int side = blockIdx.z & 1, m = blockIdx.z >> 1;
     PairWs p = pair_ws(ws, m, S);
-    const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2];
+    const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2], parity = p.cnt[CNT_PARITY];
     if (n1 <= 0 || n2 <= 0) return;
+    if (n1 <= PGX_TAIL_MAX && n2 <= PGX_TAIL_MAX) return; // the per-pair tail kernel takes it from here
     const uint32_t *dA = desc + (size_t)pairlist[2 * m] * S * words;
     const uint32_t *dB = desc + (size_t)pairlist[2 * m + 1] * S * words;
     const int nR = side ? n2 : n1, nC = side ? n1 : n2;
@@ -236,16 +238,19 @@ __device__ void select_compact_wg(PairWs p, int parity, uint32_t *wsum)
         __syncthreads();
         // reset the surviving columns' keys only after every thread evaluated col_free
         for (uint32_t q = tid; q < tot; q += nth) p.colkey[ncols[q]] = PGX_KEY_NONE;
-        if (tid == 0) p.cnt[CNT_N2] = (int)tot;
+        if (tid == 0) { p.cnt[CNT_N2] = (int)tot; p.cnt[CNT_PARITY] = parity ^ 1; }
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(SEL_NT) void k_match_select(uint32_t *ws, int S, int parity)
+__global__ __launch_bounds__(SEL_NT) void k_match_select(uint32_t *ws, int S, unsigned long long *evals)
 {
     __shared__ uint32_t wsum[SEL_NT / 64];
     PairWs p = pair_ws(ws, blockIdx.x, S);
     if (p.cnt[CNT_N1] <= 0 || p.cnt[CNT_N2] <= 0) return;
+    if (p.cnt[CNT_N1] <= PGX_TAIL_MAX && p.cnt[CNT_N2] <= PGX_TAIL_MAX) return; // round was skipped
+    const int parity = p.cnt[CNT_PARITY];
+    if (threadIdx.x == 0) atomicAdd(evals, (unsigned long long)p.cnt[CNT_N1] * (unsigned long long)p.cnt[CNT_N2]);
     select_compact_wg(p, parity, wsum);
 }
 
@@ -268,22 +273,158 @@ __device__ void bitonic_sort_wg(uint32_t *keys, uint32_t n2p)
     __syncthreads();
 }
 
+// ---- LDS-resident tail ---------------------------------------------------------------------
+// When what is left of an image pair fits (<= TAIL_MAX rows and columns) the remaining rounds
+// run out of LDS: residual descriptors, ascending index lists, best keys (local indices) and
+// alive flags.  A row's best column stays valid until that column retires, so after a round only
+// the rows (columns) whose best partner just retired are re-evaluated -- one wavefront per such
+// row, lanes striding the alive columns, wave-wide min.  Tie-heavy data (hub descriptors, equal
+// descriptors) needs many rounds of one or two acceptances; this keeps each of them ~1 us.
+constexpr int TAIL_MAX = PGX_TAIL_MAX;
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+__host__ __device__ inline size_t tail_lds_words(int W)
+{
+    // rl, cl, rbest, cbest, rdl, cdl (6 x TAIL_MAX) + alive flags (2 x TAIL_MAX bytes) + 8 counters + descriptors
+    return (size_t)6 * TAIL_MAX + (size_t)2 * TAIL_MAX / 4 + 8 + (size_t)2 * TAIL_MAX * W;
+}
+
+template <int WORDS>
+__device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict__ dA, const uint32_t *__restrict__ dB,
+                                int words_rt, uint32_t *lds)
+{
+    const int W = WORDS > 0 ? WORDS : words_rt;
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nth >> 6;
+    const int R = p.cnt[CNT_N1], C = p.cnt[CNT_N2];
+    uint32_t *rl = lds, *cl = rl + TAIL_MAX, *rbest = cl + TAIL_MAX, *cbest = rbest + TAIL_MAX;
+    uint32_t *rdl = cbest + TAIL_MAX, *cdl = rdl + TAIL_MAX;
+    uint8_t *ralive = reinterpret_cast<uint8_t *>(cdl + TAIL_MAX), *calive = ralive + TAIL_MAX;
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(calive + TAIL_MAX); // [0] dirty rows [1] dirty cols [2] accepted [3] alive rows [4] alive cols
+    uint32_t *rdesc = ctr + 8, *cdesc = rdesc + (size_t)TAIL_MAX * W;
+    const uint32_t *rows = p.rows[parity], *cols = p.cols[parity];
+
+    __syncthreads();
+    for (int i = tid; i < R; i += nth) { rl[i] = rows[i]; rdl[i] = (uint32_t)i; ralive[i] = 1; rbest[i] = PGX_KEY_NONE; }
+    for (int j = tid; j < C; j += nth) { cl[j] = cols[j]; cdl[j] = (uint32_t)j; calive[j] = 1; cbest[j] = PGX_KEY_NONE; }
+    for (int t = tid; t < R * W; t += nth) rdesc[t] = dA[(size_t)rows[t / W] * W + (t % W)];
+    for (int t = tid; t < C * W; t += nth) cdesc[t] = dB[(size_t)cols[t / W] * W + (t % W)];
+    if (tid == 0) { ctr[0] = (uint32_t)R; ctr[1] = (uint32_t)C; ctr[2] = 0; ctr[3] = 0; ctr[4] = 0; }
+    __syncthreads();
+
+    while (true) {
+        const int nrd = (int)ctr[0], ncd = (int)ctr[1];
+        // re-evaluate the dirty rows: min over alive columns of (dist, col)
+        for (int k = wv; k < nrd; k += nw) {
+            const int i = (int)rdl[k];
+            const uint32_t *a = rdesc + (size_t)i * W;
+            uint32_t best = PGX_KEY_NONE;
+            for (int j = lane; j < C; j += 64) {
+                if (!calive[j]) continue;
+                const uint32_t *b = cdesc + (size_t)j * W;
+                uint32_t d = 0;
+                if (WORDS > 0) {
+#pragma unroll
+                    for (int w = 0; w < WORDS; w++) d += __popc(a[w] ^ b[w]);
+                } else {
+                    for (int w = 0; w < W; w++) d += __popc(a[w] ^ b[w]);
+                }
+                const uint32_t key = (d << PGX_IDX_BITS) | (uint32_t)j;
+                best = key < best ? key : best;
+            }
+            best = wave_min_u32(best);
+            if (lane == 0) rbest[i] = best;
+        }
+        // and the dirty columns: min over alive rows of (dist, row)
+        for (int k = wv; k < ncd; k += nw) {
+            const int j = (int)cdl[k];
+            const uint32_t *b = cdesc + (size_t)j * W;
+            uint32_t best = PGX_KEY_NONE;
+            for (int i = lane; i < R; i += 64) {
+                if (!ralive[i]) continue;
+                const uint32_t *a = rdesc + (size_t)i * W;
+                uint32_t d = 0;
+                if (WORDS > 0) {
+#pragma unroll
+                    for (int w = 0; w < WORDS; w++) d += __popc(a[w] ^ b[w]);
+                } else {
+                    for (int w = 0; w < W; w++) d += __popc(a[w] ^ b[w]);
+                }
+                const uint32_t key = (d << PGX_IDX_BITS) | (uint32_t)i;
+                best = key < best ? key : best;
+            }
+            best = wave_min_u32(best);
+            if (lane == 0) cbest[j] = best;
+        }
+        __syncthreads();
+        if (tid == 0) { ctr[0] = 0; ctr[1] = 0; ctr[3] = 0; ctr[4] = 0; }
+        // accept mutual edges (every alive row points at an alive column here)
+        for (int i = tid; i < R; i += nth) {
+            if (!ralive[i]) continue;
+            const uint32_t rk = rbest[i];
+            const uint32_t j = rk & PGX_IDX_MASK;
+            if ((cbest[j] & PGX_IDX_MASK) == (uint32_t)i) {
+                const uint32_t oi = rl[i];
+                p.mk2[oi] = (int32_t)cl[j];
+                p.md[oi] = (int32_t)(rk >> PGX_IDX_BITS);
+                ralive[i] = 0;
+                calive[j] = 0;
+                atomicAdd(&ctr[2], 1u);
+            }
+        }
+        __syncthreads();
+        // whoever lost its partner must look again
+        for (int i = tid; i < R; i += nth) {
+            if (!ralive[i]) continue;
+            atomicAdd(&ctr[3], 1u);
+            if (!calive[rbest[i] & PGX_IDX_MASK]) rdl[atomicAdd(&ctr[0], 1u)] = (uint32_t)i;
+        }
+        for (int j = tid; j < C; j += nth) {
+            if (!calive[j]) continue;
+            atomicAdd(&ctr[4], 1u);
+            if (!ralive[cbest[j] & PGX_IDX_MASK]) cdl[atomicAdd(&ctr[1], 1u)] = (uint32_t)j;
+        }
+        __syncthreads();
+        if (ctr[3] == 0 || ctr[4] == 0) break; // uniform
+    }
+    if (tid == 0) {
+        p.cnt[CNT_NACC] += (int)ctr[2];
+        p.cnt[CNT_N1] = (int)ctr[3];
+        p.cnt[CNT_N2] = (int)ctr[4];
+    }
+    __syncthreads();
+}
+
 template <int WORDS>
 __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uint32_t *__restrict__ desc,
                                                          const int32_t *__restrict__ pairlist, int S, int words,
-                                                         int parity, pgx_pair *__restrict__ out, uint32_t lds_keys_cap)
+                                                         pgx_pair *__restrict__ out, uint32_t lds_keys_cap,
+                                                         int tail_in_lds)
 {
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wsum[SEL_NT / 64];
     const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     PairWs p = pair_ws(ws, m, S);
+    int parity = p.cnt[CNT_PARITY];
     const uint32_t *dA = desc + (size_t)pairlist[2 * m] * S * words;
     const uint32_t *dB = desc + (size_t)pairlist[2 * m + 1] * S * words;
 
-    // remaining rounds, entirely inside this workgroup
+    // rounds on the global lists while the residual is too large for LDS
     while (true) {
         const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2];
         if (n1 <= 0 || n2 <= 0) break; // uniform: cnt is only written behind barriers
+        if (tail_in_lds && n1 <= TAIL_MAX && n2 <= TAIL_MAX) {
+            tail_rounds_lds<WORDS>(p, parity, dA, dB, words, lds);
+            break;
+        }
         ham_rows_vs_cols<WORDS>(dA, p.rows[parity], n1, dB, p.cols[parity], 0, n2, 0, words, p.rowkey, false, lds);
         ham_rows_vs_cols<WORDS>(dB, p.cols[parity], n2, dA, p.rows[parity], 0, n1, 0, words, p.colkey, false, lds);
         select_compact_wg(p, parity, wsum);
@@ -324,31 +465,34 @@ size_t pgx_match_ws_bytes(int M, int stride) { return (size_t)M * pair_ws_words(
 
 template <int WORDS>
 static void launch_rounds_valu(hipStream_t s, uint32_t *ws, const uint32_t *desc, const int32_t *pairlist,
-                               const MatchPlan &plan, int parity)
+                               const MatchPlan &plan)
 {
     const int W = WORDS > 0 ? WORDS : plan.words;
     dim3 grid((plan.max_n + 255) / 256, (plan.max_n + VALU_CH - 1) / VALU_CH, plan.M * 2);
     const size_t shm = (size_t)256 * (W + 1) * 4;
-    hipLaunchKernelGGL((k_ham_valu<WORDS>), grid, dim3(256), shm, s, ws, desc, pairlist, plan.stride, plan.words, parity);
+    hipLaunchKernelGGL((k_ham_valu<WORDS>), grid, dim3(256), shm, s, ws, desc, pairlist, plan.stride, plan.words);
 }
 
 template <int WORDS>
 static void launch_finish(hipStream_t s, uint32_t *ws, const uint32_t *desc, const int32_t *pairlist,
-                          const MatchPlan &plan, int parity, pgx_pair *out)
+                          const MatchPlan &plan, pgx_pair *out)
 {
     const int W = WORDS > 0 ? WORDS : plan.words;
     const size_t ham_words = (size_t)256 * (W + 1);
-    size_t n2p = pow2_ge((size_t)(plan.max_n > 1 ? plan.max_n : 1));
-    size_t key_cap = n2p <= 32768 ? n2p : 0; // <= 128 KiB of LDS for the sort
+    const size_t n2p = pow2_ge((size_t)(plan.max_n > 1 ? plan.max_n : 1));
+    const size_t key_cap = n2p <= 32768 ? n2p : 0; // <= 128 KiB of LDS for the sort
+    const size_t tail_words = tail_lds_words(W);
+    const int tail_in_lds = tail_words * 4 <= 140 * 1024 ? 1 : 0;
     size_t shm_words = ham_words > key_cap ? ham_words : key_cap;
-    static bool attr_set = false; // per template instance
+    if (tail_in_lds && tail_words > shm_words) shm_words = tail_words;
+    static bool attr_set = false; // per template instance: allow the largest carve once
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_finish<WORDS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4 + 8192);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL((k_match_finish<WORDS>), dim3(plan.M), dim3(SEL_NT), shm_words * 4, s, ws, desc, pairlist,
-                       plan.stride, plan.words, parity, out, (uint32_t)key_cap);
+                       plan.stride, plan.words, out, (uint32_t)key_cap, tail_in_lds);
 }
 
 void pgx_launch_match(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_counts,
@@ -359,26 +503,25 @@ void pgx_launch_match(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const
     {
         ProfScope ps(ctx, "match_init");
         hipLaunchKernelGGL(k_match_init, dim3((plan.stride + 255) / 256 > 64 ? 64 : (plan.stride + 255) / 256, plan.M),
-                           dim3(256), 0, s, ws, d_counts, d_pairlist, plan.stride, status);
+                           dim3(256), 0, s, ws, d_counts, d_pairlist, plan.stride, plan.max_n, status);
     }
-    int parity = 0;
     const bool mfma_ok = (plan.words == 8) && pgx_mfma_enabled();
     for (int r = 0; r < plan.rounds_mfma; r++) {
         {
             ProfScope ps(ctx, "ham_argmin");
-            if (mfma_ok) pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan, parity);
-            else if (plan.words == 8) launch_rounds_valu<8>(s, ws, d_desc, d_pairlist, plan, parity);
-            else launch_rounds_valu<0>(s, ws, d_desc, d_pairlist, plan, parity);
+            if (mfma_ok) pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan);
+            else if (plan.words == 8) launch_rounds_valu<8>(s, ws, d_desc, d_pairlist, plan);
+            else launch_rounds_valu<0>(s, ws, d_desc, d_pairlist, plan);
         }
         {
             ProfScope ps(ctx, "match_select");
-            hipLaunchKernelGGL(k_match_select, dim3(plan.M), dim3(SEL_NT), 0, s, ws, plan.stride, parity);
+            hipLaunchKernelGGL(k_match_select, dim3(plan.M), dim3(SEL_NT), 0, s, ws, plan.stride,
+                               reinterpret_cast<unsigned long long *>(status + 4) + (r < PGX_MAX_WIDE_ROUNDS ? r : PGX_MAX_WIDE_ROUNDS - 1));
         }
-        parity ^= 1;
     }
     {
         ProfScope ps(ctx, "match_finish");
-        if (plan.words == 8) launch_finish<8>(s, ws, d_desc, d_pairlist, plan, parity, d_out);
-        else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, parity, d_out);
+        if (plan.words == 8) launch_finish<8>(s, ws, d_desc, d_pairlist, plan, d_out);
+        else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out);
     }
 }

@@ -118,7 +118,12 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     plan.M = M; plan.stride = stride; plan.words = words;
     plan.max_n = max_n > stride ? stride : (max_n < 1 ? 1 : max_n);
     // rounds on the all-CU distance kernel before the per-pair workgroup finishes the tail
-    plan.rounds_mfma = plan.max_n <= 256 ? 0 : (plan.max_n <= 1024 ? 2 : 4);
+    // all-CU rounds until the residual fits the LDS tail (random data halves per round; each launch
+    // skips image pairs that already fit, so extra rounds only cost their launch)
+    plan.rounds_mfma = 0;
+    for (int n = plan.max_n; n > PGX_TAIL_MAX && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
+    if (plan.rounds_mfma > 0 && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS) plan.rounds_mfma++;
+    HIPCHK(c, hipMemsetAsync(c->d_status + 4, 0, PGX_MAX_WIDE_ROUNDS * 8, c->stream));
     pgx_launch_match(c, c->stream, d_desc, d_counts, d_pairlist, plan, c->ws_match.p, d_out, c->d_status);
     c->last_rounds_mfma = plan.rounds_mfma;
     HIPCHK(c, hipGetLastError());
@@ -148,9 +153,9 @@ int pgx_ctx_create(int device, pgx_ctx **out)
     if (!c) return PGX_E_HIP;
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&c->d_status), 64) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->d_status), 256) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->h_status), 64, hipHostMallocDefault) != hipSuccess ||
-        hipMemset(c->d_status, 0, 64) != hipSuccess) {
+        hipMemset(c->d_status, 0, 256) != hipSuccess) {
         pgx_ctx_destroy(c);
         return PGX_E_HIP;
     }
@@ -435,12 +440,12 @@ int pgx_detect_batch_dev(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H
 }
 
 int pgx_match_batch_dev(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, int stride, int words,
-                        const int32_t *d_pairlist, int M, pgx_pair *d_out)
+                        const int32_t *d_pairlist, int M, int max_count, pgx_pair *d_out)
 {
     if (!c || !d_desc || !d_counts || !d_pairlist || !d_out || M < 0)
         return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
     Lock l(c);
-    return enqueue_match(c, d_desc, d_counts, stride, words, d_pairlist, M, stride, d_out);
+    return enqueue_match(c, d_desc, d_counts, stride, words, d_pairlist, M, max_count, d_out);
 }
 
 // ---- measurement hooks ---------------------------------------------------------------------
@@ -491,12 +496,18 @@ int pgx_profile_reset(pgx_ctx *c)
     return PGX_OK;
 }
 
-int pgx_match_stats(pgx_ctx *c, int *rounds_mfma, int64_t *evaluations)
+int pgx_match_stats(pgx_ctx *c, int *rounds_wide, int64_t *evaluations, int64_t *evaluations_round0)
 {
     if (!c) return PGX_E_BADARG;
     Lock l(c);
-    if (rounds_mfma) *rounds_mfma = c->last_rounds_mfma;
-    if (evaluations) *evaluations = c->last_evals;
+    unsigned long long ev[PGX_MAX_WIDE_ROUNDS] = {0};
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(ev, c->d_status + 4, sizeof ev, hipMemcpyDeviceToHost));
+    long long tot = 0;
+    for (int r = 0; r < c->last_rounds_mfma && r < PGX_MAX_WIDE_ROUNDS; r++) tot += (long long)ev[r];
+    if (rounds_wide) *rounds_wide = c->last_rounds_mfma;
+    if (evaluations) *evaluations = tot;
+    if (evaluations_round0) *evaluations_round0 = c->last_rounds_mfma > 0 ? (long long)ev[0] : 0;
     return PGX_OK;
 }
 

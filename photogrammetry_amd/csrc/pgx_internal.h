@@ -22,6 +22,10 @@
 #define PGX_IDX_BITS 20
 #define PGX_IDX_MASK ((1u << PGX_IDX_BITS) - 1u)
 #define PGX_KEY_NONE 0xFFFFFFFFu
+// d_status layout (ints): [0] sticky error bits, [4..4+2*PGX_MAX_WIDE_ROUNDS) u64 evaluation counters per wide round
+#define PGX_MAX_WIDE_ROUNDS 8
+// residual size (rows and columns) from which one workgroup finishes an image pair out of LDS
+#define PGX_TAIL_MAX 1024
 
 struct DevBuf {
     void *p = nullptr;

@@ -299,6 +299,22 @@ def test_match_all_equal_distances(engine):
     assert (got[:, 0] == np.arange(50)).all() and (got[:, 1] == np.arange(50)).all() and (got[:, 2] == 0).all()
 
 
+@pytest.mark.parametrize("n1,n2,protos", [(1500, 1300, 40), (600, 900, 5), (3000, 3000, 700), (1025, 1024, 3)])
+def test_match_duplicate_and_hub_descriptors(engine, n1, n2, protos):
+    """Tie chains: many identical descriptors and low-popcount "hub" descriptors, which make the
+    greedy accept one edge per cluster per round (exercises the incremental LDS tail and the
+    wide-round skip logic on both sides of the 1024 boundary)."""
+    rng = np.random.default_rng(n1 + protos)
+    base = rng.integers(0, 2**32, (protos, 8), dtype=np.uint32)
+    base[: max(1, protos // 4)] &= rng.integers(0, 2**32, (max(1, protos // 4), 8), dtype=np.uint32) & 0x11111111
+    d1 = base[rng.integers(0, protos, n1)].copy()
+    d2 = base[rng.integers(0, protos, n2)].copy()
+    flip = rng.random(n1) < 0.3
+    d1[flip, 0] ^= np.uint32(1) << rng.integers(0, 32, int(flip.sum())).astype(np.uint32)
+    got = pairs_arr(pg.KeypointMatching(engine).MatchKeypoints(d1, d2))
+    assert (got == pairs_arr(cref.match_sorted(d1, d2))).all()
+
+
 def test_match_lego_golden(engine, lego):
     """The real descriptor sets of data/feature_matching_test (2175 x 1285, tie-heavy), both directions."""
     km = pg.KeypointMatching(engine)
