@@ -187,6 +187,7 @@ def main():
             if n:
                 kern[name] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / args.steps}
         rounds_wide, evals, evals0 = eng.match_stats()
+        log("tail debug counters (pairs, sumR, sumC, rounds, row rescans, col rescans):", eng.debug_counters())
         step_ms = dt_max / args.steps * 1e3
         match_ms = sum(kern[k]["ms_per_step"] for k in ("match_init", "ham_argmin", "match_select", "match_finish") if k in kern)
         detect_ms = sum(kern[k]["ms_per_step"] for k in ("dewarp_gray", "fast", "nms", "brief") if k in kern)

@@ -132,6 +132,10 @@ int pgx_profile_reset(pgx_ctx *ctx);
  * n1*n2; evaluations_round0 = the first launch alone = sum of N1*N2).  Synchronises the stream. */
 int pgx_match_stats(pgx_ctx *ctx, int *rounds_wide, int64_t *evaluations, int64_t *evaluations_round0);
 
+/* Diagnostic counters of the match tail since the last call (pairs, sum R, sum C, rounds, row
+ * re-scans, column re-scans, 0, 0); cleared on read.  Synchronises the stream. */
+int pgx_debug_counters(pgx_ctx *ctx, int32_t *out8);
+
 /* ---- host-side helpers (no GPU work) -------------------------------------------------- */
 /* Utils.NextGaussianPair (Utils.cs:14-38) on a seeded splitmix64 stream; out [P][4]. */
 int pgx_make_brief_pairs(uint64_t seed, int sigma, int P, int32_t *out);

@@ -176,6 +176,11 @@ class Engine:
                                               _dptr(d_pairlist), int(M),
                                               int(stride if max_count is None else max_count), _dptr(d_out)))
 
+    def debug_counters(self):
+        out = np.zeros(8, dtype=np.int32)
+        self._chk(self._L.pgx_debug_counters(self._h, _ptr(out)))
+        return out.tolist()
+
     def match_stats(self):
         r, ev, ev0 = C.c_int(0), C.c_int64(0), C.c_int64(0)
         self._chk(self._L.pgx_match_stats(self._h, C.byref(r), C.byref(ev), C.byref(ev0)))

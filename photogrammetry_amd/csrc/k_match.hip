@@ -31,27 +31,35 @@ constexpr int SEL_NT = 1024;
 constexpr int CNT_N1 = 0, CNT_N2 = 1, CNT_NACC = 2, CNT_N1_ORIG = 3, CNT_N2_ORIG = 4, CNT_PARITY = 5, CNT_WORDS = 8;
 
 struct PairWs {
-    uint32_t *rowkey, *colkey, *rows[2], *cols[2];
+    uint32_t *rowkey, *colkey, *rows0, *rows1, *cols0, *cols1; // no runtime-indexed arrays: they would live in scratch
     int32_t *mk2, *md;
     int32_t *cnt;
     uint32_t *skeys;
+    uint16_t *dcache;
 };
 
 __host__ __device__ inline size_t pow2_ge(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
 
-__host__ __device__ inline size_t pair_ws_words(int S) { return (size_t)8 * S + CNT_WORDS + pow2_ge((size_t)(S > 1 ? S : 1)); }
+// per image pair: 8 arrays of S words, counters, sort keys, and the tail's cached distance
+// matrices (u16 D[R][C] and its transpose, R, C <= PGX_TAIL_MAX)
+constexpr size_t DCACHE_WORDS = (size_t)PGX_TAIL_MAX * PGX_TAIL_MAX; // 2 matrices x u16 = 1 word per entry
+__host__ __device__ inline size_t pair_ws_words(int S)
+{
+    return (size_t)8 * S + CNT_WORDS + pow2_ge((size_t)(S > 1 ? S : 1)) + DCACHE_WORDS;
+}
 
 __device__ __forceinline__ PairWs pair_ws(uint32_t *ws, int m, int S)
 {
     uint32_t *b = ws + (size_t)m * pair_ws_words(S);
     PairWs p;
     p.rowkey = b; p.colkey = b + S;
-    p.rows[0] = b + 2 * (size_t)S; p.rows[1] = b + 3 * (size_t)S;
-    p.cols[0] = b + 4 * (size_t)S; p.cols[1] = b + 5 * (size_t)S;
+    p.rows0 = b + 2 * (size_t)S; p.rows1 = b + 3 * (size_t)S;
+    p.cols0 = b + 4 * (size_t)S; p.cols1 = b + 5 * (size_t)S;
     p.mk2 = reinterpret_cast<int32_t *>(b + 6 * (size_t)S);
     p.md = reinterpret_cast<int32_t *>(b + 7 * (size_t)S);
     p.cnt = reinterpret_cast<int32_t *>(b + 8 * (size_t)S);
     p.skeys = b + 8 * (size_t)S + CNT_WORDS;
+    p.dcache = reinterpret_cast<uint16_t *>(p.skeys + pow2_ge((size_t)(S > 1 ? S : 1)));
     return p;
 }
 
@@ -67,8 +75,8 @@ __global__ __launch_bounds__(256) void k_match_init(uint32_t *ws, const int32_t 
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
         p.rowkey[i] = PGX_KEY_NONE;
         p.colkey[i] = PGX_KEY_NONE;
-        p.rows[0][i] = (uint32_t)i;
-        p.cols[0][i] = (uint32_t)i;
+        p.rows0[i] = (uint32_t)i;
+        p.cols0[i] = (uint32_t)i;
         p.mk2[i] = -1;
         p.md[i] = PGX_DIST_NONE;
     }
@@ -150,8 +158,8 @@ __global__ __launch_bounds__(256) void k_ham_valu(uint32_t *ws, const uint32_t *
     const int r_begin = blockIdx.x * 256, c_begin = blockIdx.y * VALU_CH;
     if (r_begin >= nR || c_begin >= nC) return;
     const int c_end = (c_begin + VALU_CH < nC) ? c_begin + VALU_CH : nC;
-    ham_rows_vs_cols<WORDS>(side ? dB : dA, side ? p.cols[parity] : p.rows[parity], nR, side ? dA : dB,
-                            side ? p.rows[parity] : p.cols[parity], c_begin, c_end, r_begin, words,
+    ham_rows_vs_cols<WORDS>(side ? dB : dA, side ? (parity ? p.cols1 : p.cols0) : (parity ? p.rows1 : p.rows0), nR, side ? dA : dB,
+                            side ? (parity ? p.rows1 : p.rows0) : (parity ? p.cols1 : p.cols0), c_begin, c_end, r_begin, words,
                             side ? p.colkey : p.rowkey, true, lds);
 }
 
@@ -184,8 +192,8 @@ __device__ void select_compact_wg(PairWs p, int parity, uint32_t *wsum)
 {
     const int tid = threadIdx.x, nth = blockDim.x;
     const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2];
-    const uint32_t *rows = p.rows[parity], *cols = p.cols[parity];
-    uint32_t *nrows = p.rows[parity ^ 1], *ncols = p.cols[parity ^ 1];
+    const uint32_t *rows = (parity ? p.rows1 : p.rows0), *cols = (parity ? p.cols1 : p.cols0);
+    uint32_t *nrows = (parity ? p.rows0 : p.rows1), *ncols = (parity ? p.cols0 : p.cols1);
     __syncthreads();
     // accept: row i's best column j whose best row is i
     for (int r = tid; r < n1; r += nth) {
@@ -300,71 +308,129 @@ __host__ __device__ inline size_t tail_lds_words(int W)
 
 template <int WORDS>
 __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict__ dA, const uint32_t *__restrict__ dB,
-                                int words_rt, uint32_t *lds)
+                                int words_rt, uint32_t *lds, int *dbg)
 {
     const int W = WORDS > 0 ? WORDS : words_rt;
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nth >> 6;
     const int R = p.cnt[CNT_N1], C = p.cnt[CNT_N2];
+    const int Cs = (C + 7) & ~7, Rs = (R + 7) & ~7;       // row strides of the two cached matrices (16-B rows)
+    uint16_t *D = p.dcache;                                // D[i][j], i < R, j < Cs
+    uint16_t *DT = p.dcache + (size_t)PGX_TAIL_MAX * PGX_TAIL_MAX; // DT[j][i]
     uint32_t *rl = lds, *cl = rl + TAIL_MAX, *rbest = cl + TAIL_MAX, *cbest = rbest + TAIL_MAX;
     uint32_t *rdl = cbest + TAIL_MAX, *cdl = rdl + TAIL_MAX;
     uint8_t *ralive = reinterpret_cast<uint8_t *>(cdl + TAIL_MAX), *calive = ralive + TAIL_MAX;
     uint32_t *ctr = reinterpret_cast<uint32_t *>(calive + TAIL_MAX); // [0] dirty rows [1] dirty cols [2] accepted [3] alive rows [4] alive cols
     uint32_t *rdesc = ctr + 8, *cdesc = rdesc + (size_t)TAIL_MAX * W;
-    const uint32_t *rows = p.rows[parity], *cols = p.cols[parity];
+    const uint32_t *rows = (parity ? p.rows1 : p.rows0), *cols = (parity ? p.cols1 : p.cols0);
 
+    __syncthreads();
+    for (int i = tid; i < TAIL_MAX; i += nth) { ralive[i] = 0; calive[i] = 0; }
     __syncthreads();
     for (int i = tid; i < R; i += nth) { rl[i] = rows[i]; rdl[i] = (uint32_t)i; ralive[i] = 1; rbest[i] = PGX_KEY_NONE; }
     for (int j = tid; j < C; j += nth) { cl[j] = cols[j]; cdl[j] = (uint32_t)j; calive[j] = 1; cbest[j] = PGX_KEY_NONE; }
-    for (int t = tid; t < R * W; t += nth) rdesc[t] = dA[(size_t)rows[t / W] * W + (t % W)];
-    for (int t = tid; t < C * W; t += nth) cdesc[t] = dB[(size_t)cols[t / W] * W + (t % W)];
+    // word-major images (desc[w][k]) so that lanes reading neighbouring descriptors hit neighbouring banks
+    for (int t = tid; t < R * W; t += nth) rdesc[(size_t)(t % W) * TAIL_MAX + t / W] = dA[(size_t)rows[t / W] * W + (t % W)];
+    for (int t = tid; t < C * W; t += nth) cdesc[(size_t)(t % W) * TAIL_MAX + t / W] = dB[(size_t)cols[t / W] * W + (t % W)];
     if (tid == 0) { ctr[0] = (uint32_t)R; ctr[1] = (uint32_t)C; ctr[2] = 0; ctr[3] = 0; ctr[4] = 0; }
     __syncthreads();
 
+    // one pass of xor+popcount fills both cached matrices (each entry computed twice so that
+    // both are written with coalesced rows) and the first bests
+    // (two adjacent entries per lane: one ds_read_b64 per word, one dword store per lane)
+    auto fill = [&](const uint32_t *xdesc, int nx, const uint32_t *ydesc, int ny, int ystride, uint16_t *mat, uint32_t *bestout) {
+        for (int i = wv; i < nx; i += nw) {
+            uint32_t best = PGX_KEY_NONE;
+            for (int j2 = lane * 2; j2 < ystride; j2 += 128) {
+                uint32_t d0 = 0, d1 = 0;
+                if (WORDS > 0) {
+#pragma unroll
+                    for (int w = 0; w < WORDS; w++) {
+                        const uint32_t a = xdesc[(size_t)w * TAIL_MAX + i];
+                        const uint2 b = *reinterpret_cast<const uint2 *>(ydesc + (size_t)w * TAIL_MAX + j2);
+                        d0 += __popc(a ^ b.x);
+                        d1 += __popc(a ^ b.y);
+                    }
+                } else {
+                    for (int w = 0; w < W; w++) {
+                        const uint32_t a = xdesc[(size_t)w * TAIL_MAX + i];
+                        const uint2 b = *reinterpret_cast<const uint2 *>(ydesc + (size_t)w * TAIL_MAX + j2);
+                        d0 += __popc(a ^ b.x);
+                        d1 += __popc(a ^ b.y);
+                    }
+                }
+                if (j2 < ny) {
+                    const uint32_t key = (d0 << PGX_IDX_BITS) | (uint32_t)j2;
+                    best = key < best ? key : best;
+                } else d0 = 0xFFFFu;
+                if (j2 + 1 < ny) {
+                    const uint32_t key = (d1 << PGX_IDX_BITS) | (uint32_t)(j2 + 1);
+                    best = key < best ? key : best;
+                } else d1 = 0xFFFFu;
+                *reinterpret_cast<uint32_t *>(mat + (size_t)i * ystride + j2) = d0 | (d1 << 16);
+            }
+            best = wave_min_u32(best);
+            if (lane == 0) bestout[i] = best;
+        }
+    };
+    fill(rdesc, R, cdesc, C, Cs, D, rbest);
+    fill(cdesc, C, rdesc, R, Rs, DT, cbest);
+    if (tid == 0) { ctr[0] = 0; ctr[1] = 0; }
+    __syncthreads();
+
+    // min over the alive entries of cached rows, 8 distances per 16-B load; a wavefront takes
+    // four dirty rows at a time and issues all their loads before using any (the scan is bound
+    // by L2 latency, not bandwidth)
+    auto scan_rows4 = [&](const uint16_t *mat, int stride, int n, const uint8_t *alive, const uint32_t *list,
+                          int nlist, uint32_t *bestout) {
+        for (int k0 = wv * 4; k0 < nlist; k0 += nw * 4) {
+            int idx[4];
+            uint4 v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                idx[u] = (k0 + u < nlist) ? (int)list[k0 + u] : -1;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int j8 = lane * 8 + q * 512;
+                    v[u][q] = (idx[u] >= 0 && j8 < n) ? *reinterpret_cast<const uint4 *>(mat + (size_t)idx[u] * stride + j8)
+                                                      : make_uint4(~0u, ~0u, ~0u, ~0u);
+                }
+            }
+            uint2 al[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int j8 = lane * 8 + q * 512;
+                al[q] = (j8 < n) ? *reinterpret_cast<const uint2 *>(alive + j8) : make_uint2(0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t best = PGX_KEY_NONE;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int j8 = lane * 8 + q * 512;
+                    const uint32_t dw[4] = {v[u][q].x, v[u][q].y, v[u][q].z, v[u][q].w};
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const uint32_t d = (dw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                        const uint32_t a = ((k < 4 ? al[q].x : al[q].y) >> (8 * (k & 3))) & 0xFFu;
+                        const uint32_t key = a ? ((d << PGX_IDX_BITS) | (uint32_t)(j8 + k)) : PGX_KEY_NONE;
+                        best = key < best ? key : best;
+                    }
+                }
+                best = wave_min_u32(best);
+                if (lane == 0 && idx[u] >= 0) bestout[idx[u]] = best;
+            }
+        }
+    };
+
+    if (tid == 0) { atomicAdd(&dbg[0], 1); atomicAdd(&dbg[1], R); atomicAdd(&dbg[2], C); }
     while (true) {
         const int nrd = (int)ctr[0], ncd = (int)ctr[1];
-        // re-evaluate the dirty rows: min over alive columns of (dist, col)
-        for (int k = wv; k < nrd; k += nw) {
-            const int i = (int)rdl[k];
-            const uint32_t *a = rdesc + (size_t)i * W;
-            uint32_t best = PGX_KEY_NONE;
-            for (int j = lane; j < C; j += 64) {
-                if (!calive[j]) continue;
-                const uint32_t *b = cdesc + (size_t)j * W;
-                uint32_t d = 0;
-                if (WORDS > 0) {
-#pragma unroll
-                    for (int w = 0; w < WORDS; w++) d += __popc(a[w] ^ b[w]);
-                } else {
-                    for (int w = 0; w < W; w++) d += __popc(a[w] ^ b[w]);
-                }
-                const uint32_t key = (d << PGX_IDX_BITS) | (uint32_t)j;
-                best = key < best ? key : best;
-            }
-            best = wave_min_u32(best);
-            if (lane == 0) rbest[i] = best;
-        }
-        // and the dirty columns: min over alive rows of (dist, row)
-        for (int k = wv; k < ncd; k += nw) {
-            const int j = (int)cdl[k];
-            const uint32_t *b = cdesc + (size_t)j * W;
-            uint32_t best = PGX_KEY_NONE;
-            for (int i = lane; i < R; i += 64) {
-                if (!ralive[i]) continue;
-                const uint32_t *a = rdesc + (size_t)i * W;
-                uint32_t d = 0;
-                if (WORDS > 0) {
-#pragma unroll
-                    for (int w = 0; w < WORDS; w++) d += __popc(a[w] ^ b[w]);
-                } else {
-                    for (int w = 0; w < W; w++) d += __popc(a[w] ^ b[w]);
-                }
-                const uint32_t key = (d << PGX_IDX_BITS) | (uint32_t)i;
-                best = key < best ? key : best;
-            }
-            best = wave_min_u32(best);
-            if (lane == 0) cbest[j] = best;
-        }
+        if (tid == 0) { atomicAdd(&dbg[3], 1); atomicAdd(&dbg[4], nrd); atomicAdd(&dbg[5], ncd); }
+        const unsigned long long tq0 = wall_clock64();
+        scan_rows4(D, Cs, C, calive, rdl, nrd, rbest);
+        scan_rows4(DT, Rs, R, ralive, cdl, ncd, cbest);
         __syncthreads();
+        const unsigned long long tq1 = wall_clock64();
         if (tid == 0) { ctr[0] = 0; ctr[1] = 0; ctr[3] = 0; ctr[4] = 0; }
         // accept mutual edges (every alive row points at an alive column here)
         for (int i = tid; i < R; i += nth) {
@@ -393,6 +459,7 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
             if (!ralive[cbest[j] & PGX_IDX_MASK]) cdl[atomicAdd(&ctr[1], 1u)] = (uint32_t)j;
         }
         __syncthreads();
+        if (tid == 0) { atomicAdd(&dbg[6], (int)(tq1 - tq0)); atomicAdd(&dbg[7], (int)(wall_clock64() - tq1)); }
         if (ctr[3] == 0 || ctr[4] == 0) break; // uniform
     }
     if (tid == 0) {
@@ -407,7 +474,7 @@ template <int WORDS>
 __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uint32_t *__restrict__ desc,
                                                          const int32_t *__restrict__ pairlist, int S, int words,
                                                          pgx_pair *__restrict__ out, uint32_t lds_keys_cap,
-                                                         int tail_in_lds)
+                                                         int tail_in_lds, int *status)
 {
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wsum[SEL_NT / 64];
@@ -422,11 +489,11 @@ __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uin
         const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2];
         if (n1 <= 0 || n2 <= 0) break; // uniform: cnt is only written behind barriers
         if (tail_in_lds && n1 <= TAIL_MAX && n2 <= TAIL_MAX) {
-            tail_rounds_lds<WORDS>(p, parity, dA, dB, words, lds);
+            tail_rounds_lds<WORDS>(p, parity, dA, dB, words, lds, status + 24);
             break;
         }
-        ham_rows_vs_cols<WORDS>(dA, p.rows[parity], n1, dB, p.cols[parity], 0, n2, 0, words, p.rowkey, false, lds);
-        ham_rows_vs_cols<WORDS>(dB, p.cols[parity], n2, dA, p.rows[parity], 0, n1, 0, words, p.colkey, false, lds);
+        ham_rows_vs_cols<WORDS>(dA, (parity ? p.rows1 : p.rows0), n1, dB, (parity ? p.cols1 : p.cols0), 0, n2, 0, words, p.rowkey, false, lds);
+        ham_rows_vs_cols<WORDS>(dB, (parity ? p.cols1 : p.cols0), n2, dA, (parity ? p.rows1 : p.rows0), 0, n1, 0, words, p.colkey, false, lds);
         select_compact_wg(p, parity, wsum);
         parity ^= 1;
     }
@@ -475,7 +542,7 @@ static void launch_rounds_valu(hipStream_t s, uint32_t *ws, const uint32_t *desc
 
 template <int WORDS>
 static void launch_finish(hipStream_t s, uint32_t *ws, const uint32_t *desc, const int32_t *pairlist,
-                          const MatchPlan &plan, pgx_pair *out)
+                          const MatchPlan &plan, pgx_pair *out, int *status)
 {
     const int W = WORDS > 0 ? WORDS : plan.words;
     const size_t ham_words = (size_t)256 * (W + 1);
@@ -492,7 +559,7 @@ static void launch_finish(hipStream_t s, uint32_t *ws, const uint32_t *desc, con
         attr_set = true;
     }
     hipLaunchKernelGGL((k_match_finish<WORDS>), dim3(plan.M), dim3(SEL_NT), shm_words * 4, s, ws, desc, pairlist,
-                       plan.stride, plan.words, out, (uint32_t)key_cap, tail_in_lds);
+                       plan.stride, plan.words, out, (uint32_t)key_cap, tail_in_lds, status);
 }
 
 void pgx_launch_match(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_counts,
@@ -521,7 +588,7 @@ void pgx_launch_match(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const
     }
     {
         ProfScope ps(ctx, "match_finish");
-        if (plan.words == 8) launch_finish<8>(s, ws, d_desc, d_pairlist, plan, d_out);
-        else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out);
+        if (plan.words == 8) launch_finish<8>(s, ws, d_desc, d_pairlist, plan, d_out, status);
+        else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out, status);
     }
 }

@@ -14,7 +14,7 @@
 //   k_nms_count / k_nms_cellscan / k_nms_scatter   counting sort of the points into a uniform
 //        grid of cells >= r, all per-point arrays re-ordered into cell order so a neighbour
 //        scan reads three contiguous runs;
-//   WIDE_ROUNDS x (k_nms_phase_a, k_nms_phase_b)   one thread per point, whole chip;
+//   WIDE_ROUNDS x k_nms_phase_cell<0>, <1>   one wavefront per cell, whole chip;
 //   k_nms_tail   one 1024-thread workgroup per frame: finishes the few points still undecided
 //        (rounds with an active list), then sorts the accepted points (bitonic, LDS) and
 //        writes the order.
@@ -24,7 +24,7 @@
 namespace {
 
 constexpr int NT = 1024;
-constexpr int WIDE_ROUNDS = 5;
+constexpr int WIDE_ROUNDS = 10;
 constexpr uint32_t SORT_LDS_MAX = 16384; // u64 keys -> 128 KiB
 
 struct NmsLayout {
@@ -226,32 +226,109 @@ __device__ __forceinline__ bool point_suppressed(const NmsPtrs &P, const NmsLayo
     return false;
 }
 
-__global__ __launch_bounds__(256) void k_nms_phase_a(const int32_t *__restrict__ n_raw_all, int n_cap, int W, int H,
-                                                     int radius, unsigned char *ws_all, size_t ws_stride)
-{
-    const int f = blockIdx.y;
-    const int n = clamp_n(n_raw_all, f, n_cap);
-    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-    if ((int)p >= n) return;
-    const NmsLayout L = nms_layout(W, H, radius, n_cap);
-    NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
-    if (P.state[p] != ST_UNDECIDED) return;
-    if (!point_beaten(P, L, p, (long long)radius * radius)) P.state[p] = ST_NEW;
-}
+// One wavefront per grid cell.  Lanes hold the 3x3-cell neighbourhood (three contiguous runs in
+// cell order) in registers, 64 x NB_REG neighbours per pass; the wave then walks the cell's own
+// undecided points one at a time -- every lane tests its neighbours against the broadcast centre
+// and a ballot decides -- so work is (undecided centres) x (neighbours / 64) wave-instructions with
+// all lanes busy, instead of (neighbours) x (centres / 64).
+// PHASE 0 = "is a better undecided point within r" (phase A), PHASE 1 = "is an accepted point
+// within r" (phase B, which also retires this cell's NEW marks to ACCEPTED).
+constexpr int NB_REG = 4;     // neighbour registers per lane and pass (256 neighbours)
+constexpr int CEN_MAX = 64;   // centre points staged per batch
 
-__global__ __launch_bounds__(256) void k_nms_phase_b(const int32_t *__restrict__ n_raw_all, int n_cap, int W, int H,
-                                                     int radius, unsigned char *ws_all, size_t ws_stride)
+template <int PHASE>
+__global__ __launch_bounds__(256) void k_nms_phase_cell(const int32_t *__restrict__ n_raw_all, int n_cap, int W, int H,
+                                                        int radius, unsigned char *ws_all, size_t ws_stride)
 {
-    const int f = blockIdx.y;
-    const int n = clamp_n(n_raw_all, f, n_cap);
-    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-    if ((int)p >= n) return;
+    __shared__ uint32_t c_xy[4][CEN_MAX];
+    __shared__ int32_t c_score[4][CEN_MAX];
+    __shared__ uint32_t c_idx[4][CEN_MAX];
+    __shared__ uint32_t c_flag[4][CEN_MAX]; // bit0: undecided at entry, bit1: hit
+    const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (clamp_n(n_raw_all, f, n_cap) == 0) return;
     const NmsLayout L = nms_layout(W, H, radius, n_cap);
+    const int c = blockIdx.x * 4 + wv;
+    if (c >= L.ncell) return; // wave-uniform
     NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
-    const uint8_t st = P.state[p];
-    if (st == ST_NEW) { P.state[p] = ST_ACCEPTED; return; } // NEW and ACCEPTED both read as "accepted" in this phase
-    if (st != ST_UNDECIDED) return;
-    if (point_suppressed(P, L, p, (long long)radius * radius)) P.state[p] = ST_SUPPRESSED;
+    const uint32_t p0 = P.cell_start[c], p1 = P.cell_start[c + 1];
+    if (p0 == p1) return;
+    const long long r2 = (long long)radius * (long long)radius;
+    const int cy = c / L.gw, cx = c - cy * L.gw;
+    const int cx0 = cx > 0 ? cx - 1 : 0, cx1 = cx + 1 < L.gw ? cx + 1 : L.gw - 1;
+    // the three neighbour runs (rows cy-1, cy, cy+1 of cells), as one flat index space
+    uint32_t rq[3], rlen[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int yy = cy - 1 + k;
+        if (yy < 0 || yy >= L.gh) { rq[k] = 0; rlen[k] = 0; continue; }
+        rq[k] = P.cell_start[yy * L.gw + cx0];
+        rlen[k] = P.cell_start[yy * L.gw + cx1 + 1] - rq[k];
+    }
+    const uint32_t ntot = rlen[0] + rlen[1] + rlen[2];
+
+    for (uint32_t pb = p0; pb < p1; pb += CEN_MAX) { // centre batches
+        const uint32_t p = pb + lane;
+        const bool have = p < p1;
+        uint8_t st = have ? P.state[p] : (uint8_t)ST_SUPPRESSED;
+        if (PHASE == 1 && have && st == ST_NEW) { P.state[p] = ST_ACCEPTED; st = ST_ACCEPTED; }
+        const bool und = have && st == ST_UNDECIDED;
+        if (!__any(und)) continue;
+        __builtin_amdgcn_wave_barrier();
+        c_flag[wv][lane] = und ? 1u : 0u;
+        if (und) {
+            c_xy[wv][lane] = P.s_xy[p];
+            if (PHASE == 0) { c_score[wv][lane] = P.s_score[p]; c_idx[wv][lane] = P.s_idx[p]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int ncen = (int)((p1 - pb < (uint32_t)CEN_MAX) ? p1 - pb : (uint32_t)CEN_MAX);
+
+        for (uint32_t nb0 = 0; nb0 < ntot; nb0 += 64 * NB_REG) { // neighbour passes
+            uint32_t nq[NB_REG], nxy[NB_REG], nid[NB_REG];
+            int32_t nsc[NB_REG];
+            bool nok[NB_REG];
+#pragma unroll
+            for (int k = 0; k < NB_REG; k++) {
+                const uint32_t fi = nb0 + k * 64 + lane;
+                bool ok = fi < ntot;
+                uint32_t q = 0;
+                if (ok) q = fi < rlen[0] ? rq[0] + fi : (fi < rlen[0] + rlen[1] ? rq[1] + (fi - rlen[0]) : rq[2] + (fi - rlen[0] - rlen[1]));
+                uint8_t sq = ok ? P.state[q] : (uint8_t)ST_SUPPRESSED;
+                if (PHASE == 0) ok = ok && (sq == ST_UNDECIDED || sq == ST_NEW); // NEW was undecided when the round began
+                else ok = ok && (sq == ST_NEW || sq == ST_ACCEPTED);
+                nq[k] = q;
+                nok[k] = ok;
+                nxy[k] = ok ? P.s_xy[q] : 0u;
+                if (PHASE == 0) { nsc[k] = ok ? P.s_score[q] : 0; nid[k] = ok ? P.s_idx[q] : 0u; }
+            }
+            const int nchunks = (int)(((ntot - nb0 < (uint32_t)(64 * NB_REG) ? ntot - nb0 : (uint32_t)(64 * NB_REG)) + 63) / 64);
+            for (int k = 0; k < ncen; k++) {
+                const uint32_t fl = c_flag[wv][k];
+                if (fl != 1u) continue; // decided, or already hit in an earlier pass (uniform)
+                const uint32_t cxy = c_xy[wv][k];
+                const int x = (int)(cxy & 0xFFFFu), y = (int)(cxy >> 16);
+                const int sc = PHASE == 0 ? c_score[wv][k] : 0;
+                const uint32_t id = PHASE == 0 ? c_idx[wv][k] : 0u;
+                bool hit = false;
+#pragma unroll
+                for (int j = 0; j < NB_REG; j++) {
+                    if (j >= nchunks) break; // uniform
+                    const long long dx = (int)(nxy[j] & 0xFFFFu) - x, dy = (int)(nxy[j] >> 16) - y;
+                    bool h = nok[j] && (dx * dx + dy * dy <= r2);
+                    if (PHASE == 0) h = h && nq[j] != pb + (uint32_t)k && better(nsc[j], nid[j], sc, id);
+                    hit = hit || h;
+                }
+                if (__any(hit)) { if (lane == 0) c_flag[wv][k] = 3u; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // decisions of this batch
+        if (und) {
+            const bool hit = (c_flag[wv][lane] & 2u) != 0u;
+            if (PHASE == 0) { if (!hit) P.state[p] = ST_NEW; }
+            else { if (hit) P.state[p] = ST_SUPPRESSED; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 __device__ void bitonic_sort_u64(unsigned long long *keys, uint32_t n2p)
@@ -401,6 +478,7 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
     const NmsLayout L = nms_layout(W, H, radius, n_cap);
     const bool rounds = radius >= 0;
     const dim3 pgrid((n_cap + 255) / 256, F);
+    const dim3 cgrid((L.ncell + 3) / 4, F);
     if (rounds) {
         hipLaunchKernelGGL(k_nms_zero, dim3((L.ncell + 256) / 256, F), dim3(256), 0, s, n_cap, W, H, radius, ws, ws_stride);
         hipLaunchKernelGGL(k_nms_count, pgrid, dim3(256), 0, s, raw_xy, n_raw, n_cap, W, H, radius, ws, ws_stride);
@@ -408,8 +486,8 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
         hipLaunchKernelGGL(k_nms_scatter, pgrid, dim3(256), 0, s, raw_xy, raw_score, n_raw, n_cap, W, H, radius, ws,
                            ws_stride);
         for (int r = 0; r < WIDE_ROUNDS; r++) {
-            hipLaunchKernelGGL(k_nms_phase_a, pgrid, dim3(256), 0, s, n_raw, n_cap, W, H, radius, ws, ws_stride);
-            hipLaunchKernelGGL(k_nms_phase_b, pgrid, dim3(256), 0, s, n_raw, n_cap, W, H, radius, ws, ws_stride);
+            hipLaunchKernelGGL(k_nms_phase_cell<0>, cgrid, dim3(256), 0, s, n_raw, n_cap, W, H, radius, ws, ws_stride);
+            hipLaunchKernelGGL(k_nms_phase_cell<1>, cgrid, dim3(256), 0, s, n_raw, n_cap, W, H, radius, ws, ws_stride);
         }
     }
     static bool attr_set = false;

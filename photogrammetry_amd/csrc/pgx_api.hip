@@ -113,18 +113,24 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     if (M <= 0) return PGX_OK;
     if (stride <= 0 || stride > (1 << PGX_IDX_BITS)) return fail(c, PGX_E_BADARG, "stride must be in [1, 2^20]");
     if (words <= 0 || words > 127) return fail(c, PGX_E_BADARG, "words must be in [1, 127] (P <= 4064)");
-    HIPCHK(c, c->ws_match.ensure(pgx_match_ws_bytes(M, stride)));
+    // image pairs go through in chunks so the per-pair workspace (incl. the tail's 4 MiB distance cache) stays bounded
+    const int CHUNK = 256;
+    const int mc = M < CHUNK ? M : CHUNK;
+    HIPCHK(c, c->ws_match.ensure(pgx_match_ws_bytes(mc, stride)));
     MatchPlan plan;
-    plan.M = M; plan.stride = stride; plan.words = words;
+    plan.stride = stride; plan.words = words;
     plan.max_n = max_n > stride ? stride : (max_n < 1 ? 1 : max_n);
-    // rounds on the all-CU distance kernel before the per-pair workgroup finishes the tail
     // all-CU rounds until the residual fits the LDS tail (random data halves per round; each launch
     // skips image pairs that already fit, so extra rounds only cost their launch)
     plan.rounds_mfma = 0;
     for (int n = plan.max_n; n > PGX_TAIL_MAX && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
     if (plan.rounds_mfma > 0 && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS) plan.rounds_mfma++;
     HIPCHK(c, hipMemsetAsync(c->d_status + 4, 0, PGX_MAX_WIDE_ROUNDS * 8, c->stream));
-    pgx_launch_match(c, c->stream, d_desc, d_counts, d_pairlist, plan, c->ws_match.p, d_out, c->d_status);
+    for (int m0 = 0; m0 < M; m0 += CHUNK) {
+        plan.M = (M - m0 < CHUNK) ? M - m0 : CHUNK;
+        pgx_launch_match(c, c->stream, d_desc, d_counts, d_pairlist + 2 * (size_t)m0, plan, c->ws_match.p,
+                         d_out + (size_t)m0 * stride, c->d_status);
+    }
     c->last_rounds_mfma = plan.rounds_mfma;
     HIPCHK(c, hipGetLastError());
     return PGX_OK;
@@ -493,6 +499,16 @@ int pgx_profile_reset(pgx_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_drain(c);
     c->prof.clear();
+    return PGX_OK;
+}
+
+int pgx_debug_counters(pgx_ctx *c, int32_t *out8)
+{
+    if (!c || !out8) return PGX_E_BADARG;
+    Lock l(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out8, c->d_status + 24, 32, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemset(c->d_status + 24, 0, 32));
     return PGX_OK;
 }
 
