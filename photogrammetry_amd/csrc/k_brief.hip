@@ -15,6 +15,34 @@ namespace {
 
 constexpr int MAX_WORDS = 128; // P <= 4096
 
+// P == 256 fast path: all four pair loads, then all eight gathers, are issued before any is used
+// (the generic loop below waits for each 64-pair chunk in turn: 4 dependent L2 round trips).
+__device__ __forceinline__ void brief_256(const float *__restrict__ g, int W, int H, int x, int y,
+                                          const int4 *__restrict__ pairs, uint32_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    int4 pr[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) pr[c] = pairs[c * 64 + lane];
+    float v1[4], v2[4];
+    bool ok[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int x1 = x + pr[c].x, y1 = y + pr[c].y, x2 = x + pr[c].z, y2 = y + pr[c].w;
+        ok[c] = x1 >= 0 && x1 < W && y1 >= 0 && y1 < H && x2 >= 0 && x2 < W && y2 >= 0 && y2 < H; // Keypoint.cs:39-45
+        v1[c] = ok[c] ? g[(size_t)y1 * W + x1] : 0.f;
+        v2[c] = ok[c] ? g[(size_t)y2 * W + x2] : 0.f;
+    }
+    unsigned long long rev[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) rev[c] = __brevll(__ballot(ok[c] && v1[c] < v2[c])); // :50; bits [192-64c, 256-64c)
+    if (lane < 8) {
+        const int q = lane >> 1; // 64-bit piece q of the descriptor comes from chunk 3 - q (selects, not a runtime index)
+        const unsigned long long r = q == 0 ? rev[3] : (q == 1 ? rev[2] : (q == 2 ? rev[1] : rev[0]));
+        out[lane] = (lane & 1) ? (uint32_t)(r >> 32) : (uint32_t)r;
+    }
+}
+
 __device__ __forceinline__ void brief_one(const float *__restrict__ g, int W, int H, int x, int y,
                                           const int4 *__restrict__ pairs, int P, int words, uint32_t *wbuf /*LDS*/,
                                           uint32_t *__restrict__ out)
@@ -77,7 +105,8 @@ __global__ __launch_bounds__(256) void k_brief_kept(const float *__restrict__ gr
         kp.value = g[(size_t)y * W + x]; // Keypoint.cs:26
         kp_out[(size_t)f * kp_cap + k] = kp;
     }
-    brief_one(g, W, H, x, y, pairs, P, words, wbuf[wv], desc_out + ((size_t)f * kp_cap + k) * words);
+    if (P == 256) brief_256(g, W, H, x, y, pairs, desc_out + ((size_t)f * kp_cap + k) * 8);
+    else brief_one(g, W, H, x, y, pairs, P, words, wbuf[wv], desc_out + ((size_t)f * kp_cap + k) * words);
 }
 
 __global__ __launch_bounds__(256) void k_brief_list(const float *__restrict__ gray, int W, int H,
@@ -89,7 +118,8 @@ __global__ __launch_bounds__(256) void k_brief_list(const float *__restrict__ gr
     const int wv = threadIdx.x >> 6;
     const int k = blockIdx.x * 4 + wv;
     if (k >= n) return;
-    brief_one(gray, W, H, kps[k].x, kps[k].y, pairs, P, words, wbuf[wv], desc_out + (size_t)k * words);
+    if (P == 256) brief_256(gray, W, H, kps[k].x, kps[k].y, pairs, desc_out + (size_t)k * 8);
+    else brief_one(gray, W, H, kps[k].x, kps[k].y, pairs, P, words, wbuf[wv], desc_out + (size_t)k * words);
 }
 
 } // namespace

@@ -1,0 +1,125 @@
+"""Multi-GPU plumbing for the path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+
+The reference handles exactly one image pair in one process (TestService.cs:80-96): nothing in
+it couples image pairs, so the path shards with no data-path collective inside detect or match:
+
+  phase 1  detect      frame f      -> rank f mod G        (independent per frame)
+  phase 2  exchange    ONE all-gather of fixed-size per-frame records {count, descriptors}
+  phase 3  match       image pair p -> rank p mod G        (independent per image pair)
+  phase 4  exchange    ONE all-gather of the match lists; fixed size because the reference always
+                       emits exactly N1 entries per image pair (KeypointMatching.cs:38)
+
+The gathered lists feed the track graph (union-find over (frame, keypoint) nodes), which the
+reference does not have and which lives on the host.
+Only tensors cross this module; it never touches the oracle.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def owner(index, world):
+    return index % world
+
+
+def local_items(n, rank, world):
+    """Indices owned by `rank` under round-robin sharding."""
+    return list(range(rank, n, world))
+
+
+def slots(n, world):
+    """Per-rank slot count (the last slots of some ranks are padding)."""
+    return (n + world - 1) // world
+
+
+def all_pairs(n_frames):
+    """Ordered image pairs i < j of a sequence, the enumeration order of SURVEY 8d config 3."""
+    return [(i, j) for i in range(n_frames) for j in range(i + 1, n_frames)]
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def all_gather_slots(local, n_total):
+    """local: [slots(n_total, G), ...] holding this rank's items in ownership order (item k of rank
+    r is global index r + k*G).  Returns [n_total, ...] in global order on every rank.
+    One fixed-size all_gather (no all-gatherv: records are padded to a common size)."""
+    rank, world = _world()
+    if world == 1:
+        return local[:n_total].clone()
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local.contiguous())
+    out = torch.empty((n_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        idx = local_items(n_total, r, world)
+        if idx:
+            out[torch.as_tensor(idx, device=local.device)] = gathered[r][:len(idx)]
+    return out
+
+
+def exchange_descriptors(desc_local, counts_local, n_frames):
+    """Phase 2.  desc_local [slots][cap][words] int32, counts_local [slots] int32 ->
+    (desc_all [F][cap][words], counts_all [F]) identical on every rank."""
+    return all_gather_slots(desc_local, n_frames), all_gather_slots(counts_local, n_frames)
+
+
+def exchange_matches(out_local, n_pairs):
+    """Phase 4.  out_local [slots][cap][3] int32 -> [M][cap][3] on every rank."""
+    return all_gather_slots(out_local, n_pairs)
+
+
+class TrackGraph:
+    """Union-find over (frame, keypoint) nodes fed by the gathered match lists.  A match (k1, k2,
+    dist) of image pair (a, b) links node (a, k1) with (b, k2) when dist <= max_dist (the distance
+    gate the live C# matcher lacks).  Tracks that would contain two keypoints of the
+    same frame are split by refusing the offending union (first come, in list order)."""
+
+    def __init__(self, counts):
+        self.counts = [int(c) for c in counts]
+        self.base = np.concatenate([[0], np.cumsum(self.counts)]).astype(np.int64)
+        n = int(self.base[-1])
+        self.parent = np.arange(n, dtype=np.int64)
+        self.frames = [{int(f)} for f, c in enumerate(self.counts) for _ in range(c)]
+
+    def node(self, frame, k):
+        return int(self.base[frame] + k)
+
+    def find(self, x):
+        p = self.parent
+        while p[x] != x:
+            p[x] = p[p[x]]
+            x = p[x]
+        return int(x)
+
+    def add_pair(self, a, b, matches, max_dist):
+        """matches: [N1][3] (k1, k2, dist) for frames (a, b)."""
+        for k1, k2, d in np.asarray(matches).reshape(-1, 3):
+            if d > max_dist or k1 >= self.counts[a] or k2 >= self.counts[b]:
+                continue
+            ra, rb = self.find(self.node(a, int(k1))), self.find(self.node(b, int(k2)))
+            if ra == rb or (self.frames[ra] & self.frames[rb]):
+                continue
+            self.parent[rb] = ra
+            self.frames[ra] |= self.frames[rb]
+
+    def tracks(self, min_len=2):
+        """Sorted list of tracks, each a sorted list of (frame, keypoint)."""
+        groups = {}
+        for f, c in enumerate(self.counts):
+            for k in range(c):
+                groups.setdefault(self.find(self.node(f, k)), []).append((f, k))
+        return sorted(sorted(g) for g in groups.values() if len(g) >= min_len)
+
+
+def build_track_graph(counts_all, pair_list, matches_all, max_dist=64):
+    """counts_all [F]; pair_list [(a, b)]; matches_all [M][cap][3] (tensor or array)."""
+    m = matches_all.cpu().numpy() if isinstance(matches_all, torch.Tensor) else np.asarray(matches_all)
+    c = counts_all.cpu().numpy() if isinstance(counts_all, torch.Tensor) else np.asarray(counts_all)
+    g = TrackGraph(c)
+    for p, (a, b) in enumerate(pair_list):
+        g.add_pair(a, b, m[p][:int(c[a])], max_dist)
+    return g

@@ -1,0 +1,135 @@
+"""CPU tests of the N > 1 path: world_size-2 `gloo` process groups exercising the sharding and the
+two all-gathers of photogrammetry_amd/dist.py.  The GPU compute of each rank is stood in for by the
+CPU oracle (allowed here: tests may use the oracle as the checker / stand-in), so what is verified is
+that a pair-sharded run reproduces the single-process result exactly, including the track graph."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import cref
+from photogrammetry_amd import dist as pdist
+from photogrammetry_amd import synth
+
+W, H, CAP, RADIUS = 200, 140, 256, 9
+T = np.float32(0.1)
+N_FRAMES = 5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _frames():
+    base = synth.make_frame(W, H, seed=3, n_shapes=120)
+    return [synth.shift_frame(base, 3 * i, i) for i in range(N_FRAMES)]
+
+
+def _detect(frame, pairs):
+    g = cref.gray(frame)
+    raw = cref.detect(g, T)
+    kept = raw[cref.nms(raw, RADIUS)][:CAP]
+    desc = np.zeros((CAP, 8), dtype=np.uint32)
+    desc[:len(kept)] = cref.brief(g, np.stack([kept["x"], kept["y"]], 1), pairs)
+    return desc.view(np.int32), len(kept)
+
+
+def _match(desc_a, n_a, desc_b, n_b):
+    out = np.zeros((CAP, 3), dtype=np.int32)
+    out[:, 2] = cref.INT_MAX
+    if n_a:
+        m = cref.match(desc_a[:n_a].view(np.uint32), desc_b[:n_b].view(np.uint32))
+        out[:n_a] = np.stack([m["k1"], m["k2"], m["dist"]], 1)
+    return out
+
+
+def _single_process():
+    pairs = cref.gaussian_pairs(0, 20, 256)
+    fr = _frames()
+    det = [_detect(f, pairs) for f in fr]
+    desc = np.stack([d for d, _ in det])
+    counts = np.array([n for _, n in det], dtype=np.int32)
+    pl = pdist.all_pairs(N_FRAMES)
+    matches = np.stack([_match(desc[a], counts[a], desc[b], counts[b]) for a, b in pl])
+    return desc, counts, pl, matches
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pairs = cref.gaussian_pairs(0, 20, 256)
+        fr = _frames()
+        # phase 1: detect the frames this rank owns
+        mine = pdist.local_items(N_FRAMES, rank, world)
+        ns = pdist.slots(N_FRAMES, world)
+        desc_l = torch.zeros((ns, CAP, 8), dtype=torch.int32)
+        cnt_l = torch.zeros(ns, dtype=torch.int32)
+        for k, f in enumerate(mine):
+            d, n = _detect(fr[f], pairs)
+            desc_l[k] = torch.from_numpy(d)
+            cnt_l[k] = n
+        # phase 2: one all-gather of the per-frame records
+        desc_all, cnt_all = pdist.exchange_descriptors(desc_l, cnt_l, N_FRAMES)
+        # phase 3: match the image pairs this rank owns
+        pl = pdist.all_pairs(N_FRAMES)
+        mine_p = pdist.local_items(len(pl), rank, world)
+        out_l = torch.zeros((pdist.slots(len(pl), world), CAP, 3), dtype=torch.int32)
+        da, ca = desc_all.numpy(), cnt_all.numpy()
+        for k, p in enumerate(mine_p):
+            a, b = pl[p]
+            out_l[k] = torch.from_numpy(_match(da[a], ca[a], da[b], ca[b]))
+        # phase 4: one all-gather of the match lists
+        out_all = pdist.exchange_matches(out_l, len(pl))
+        g = pdist.build_track_graph(cnt_all, pl, out_all, max_dist=40)
+        q.put((rank, desc_all.numpy(), cnt_all.numpy(), out_all.numpy(), g.tracks()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_pair_sharded_run_equals_single_process():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    desc, counts, pl, matches = _single_process()
+    ref_tracks = pdist.build_track_graph(counts, pl, matches, max_dist=40).tracks()
+    assert len(ref_tracks) > 5
+    for rank, d, c, m, tracks in results:
+        assert (d == desc).all() and (c == counts).all(), rank
+        assert (m == matches).all(), rank
+        assert tracks == ref_tracks, rank
+
+
+def test_sharding_helpers():
+    assert pdist.local_items(7, 1, 3) == [1, 4]
+    assert pdist.slots(7, 3) == 3 and pdist.slots(6, 3) == 2
+    assert pdist.all_pairs(4) == [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    # world 1: the "gather" is the identity on the owned prefix
+    t = torch.arange(12, dtype=torch.int32).reshape(4, 3)
+    assert (pdist.all_gather_slots(t, 3) == t[:3]).all()
+
+
+def test_track_graph_rejects_same_frame_merges():
+    g = pdist.TrackGraph([2, 2, 2])
+    g.add_pair(0, 1, [[0, 0, 5], [1, 1, 99]], max_dist=10)       # second edge fails the distance gate
+    g.add_pair(1, 2, [[0, 1, 3]], max_dist=10)
+    g.add_pair(0, 2, [[1, 1, 2]], max_dist=10)                   # would put (0,0) and (0,1) in one track
+    assert g.tracks() == [[(0, 0), (1, 0), (2, 1)]]
