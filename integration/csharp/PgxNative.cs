@@ -1,0 +1,59 @@
+// PgxNative.cs -- P/Invoke surface of libpgx.so (include/pgx.h), to be added to
+// dotnet_src/ImageProcessing.  NOT compiled in this repository (no .NET SDK in the build image);
+// it is the literal binding a maintainer adds.  See INTEGRATION.md.
+using System;
+using System.Runtime.InteropServices;
+
+namespace ImageProcessing.Native;
+
+[StructLayout(LayoutKind.Sequential)]
+public struct PgxKeypoint { public int X, Y, FastScore; public float Value; }
+
+[StructLayout(LayoutKind.Sequential)]
+public struct PgxPair { public int K1, K2, Dist; }
+
+internal static unsafe class PgxNative
+{
+    private const string Lib = "pgx"; // libpgx.so next to the executable or on LD_LIBRARY_PATH
+
+    public const int Ok = 0, EDimMismatch = 1, EOobSource = 2, EEmptySet = 3, ECapacity = 4, EBadArg = 5, EHip = 6,
+        ENotConfigured = 7;
+
+    [DllImport(Lib)] public static extern int pgx_ctx_create(int device, out IntPtr ctx);
+    [DllImport(Lib)] public static extern void pgx_ctx_destroy(IntPtr ctx);
+    [DllImport(Lib)] public static extern IntPtr pgx_last_error(IntPtr ctx);
+    [DllImport(Lib)] public static extern int pgx_set_dewarp_map(IntPtr ctx, int* uv, int w, int h);
+    [DllImport(Lib)] public static extern int pgx_set_brief_pairs(IntPtr ctx, int* pairs, int p);
+    [DllImport(Lib)] public static extern int pgx_set_detect_params(IntPtr ctx, float threshold, int suppressionRadius);
+    [DllImport(Lib)] public static extern int pgx_set_capacity(IntPtr ctx, int maxRaw, int maxKeypoints);
+    [DllImport(Lib)] public static extern int pgx_dewarp(IntPtr ctx, ushort* rgba64, int w, int h, ushort* outRgba64);
+    [DllImport(Lib)] public static extern int pgx_gray(IntPtr ctx, ushort* rgba64, int w, int h, float* outGray);
+    [DllImport(Lib)] public static extern int pgx_fast(IntPtr ctx, float* gray, int w, int h, PgxKeypoint* o, int capacity, out int n);
+    [DllImport(Lib)] public static extern int pgx_brief(IntPtr ctx, float* gray, int w, int h, PgxKeypoint* kps, int n, uint* desc);
+    [DllImport(Lib)] public static extern int pgx_nms(IntPtr ctx, PgxKeypoint* kps, int n, int w, int h, int* order, out int nOut);
+    [DllImport(Lib)] public static extern int pgx_match(IntPtr ctx, uint* d1, int n1, uint* d2, int n2, int words, PgxPair* o);
+    [DllImport(Lib)] public static extern int pgx_detect(IntPtr ctx, ushort* rgba64, int w, int h, PgxKeypoint* kp, uint* desc,
+                                                         int capacity, out int n, out int nRaw);
+
+    /// <summary>Maps a status code back to the exception type the managed implementation throws.</summary>
+    public static void Check(IntPtr ctx, int rc)
+    {
+        if (rc == Ok) return;
+        var msg = Marshal.PtrToStringUTF8(pgx_last_error(ctx)) ?? "pgx error";
+        throw rc switch
+        {
+            EDimMismatch or EBadArg => new ArgumentException(msg),          // DeWarp.cs:23, :48
+            EOobSource => new IndexOutOfRangeException(msg),                // Matrix.cs:65, :207
+            EEmptySet => new ArgumentOutOfRangeException(msg),              // KeypointMatching.cs:61
+            _ => new InvalidOperationException(msg),
+        };
+    }
+}
+
+/// <summary>One context per GPU; registered as a DI singleton (Program.cs:40-59).</summary>
+public sealed class PgxContext : IDisposable
+{
+    internal IntPtr Handle;
+    public PgxContext(int device = 0) => PgxNative.Check(IntPtr.Zero, PgxNative.pgx_ctx_create(device, out Handle));
+    public void Dispose() { if (Handle != IntPtr.Zero) { PgxNative.pgx_ctx_destroy(Handle); Handle = IntPtr.Zero; } }
+}
