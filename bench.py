@@ -182,14 +182,14 @@ def main():
 
     if rank == 0:
         kern = {}
-        for name in ("dewarp_gray", "fast", "nms", "brief", "match_init", "ham_argmin", "match_select", "match_finish"):
+        for name in ("dewarp_gray", "fast", "nms", "brief", "match_init", "ham_argmin", "match_select", "tail_fill", "match_finish"):
             n, ms = eng.profile_get(name)
             if n:
                 kern[name] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / args.steps}
         rounds_wide, evals, evals0 = eng.match_stats()
         log("tail debug counters (pairs, sumR, sumC, rounds, row rescans, col rescans):", eng.debug_counters())
         step_ms = dt_max / args.steps * 1e3
-        match_ms = sum(kern[k]["ms_per_step"] for k in ("match_init", "ham_argmin", "match_select", "match_finish") if k in kern)
+        match_ms = sum(kern[k]["ms_per_step"] for k in ("match_init", "ham_argmin", "match_select", "tail_fill", "match_finish") if k in kern)
         detect_ms = sum(kern[k]["ms_per_step"] for k in ("dewarp_gray", "fast", "nms", "brief") if k in kern)
         dominant = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
         npix = W * H

@@ -33,15 +33,28 @@ __global__ __launch_bounds__(256) void k_fast_planes(const float *__restrict__ g
     const float *g = gray + (size_t)f * W * H;
     const int x0 = tx * TW - HALO, y0 = ty * TH - HALO;
 
-    for (int r = wv; r < LROWS; r += 4) {
-        const int gy = y0 + r;
-        const bool rowok = gy >= 0 && gy < H;
-        const float *grow = g + (size_t)(rowok ? gy : 0) * W;
-        int gx = x0 + lane;
-        tile[r][lane] = (rowok && gx >= 0 && gx < W) ? grow[gx] : 0.0f;
-        if (lane < 2 * HALO) {
-            gx = x0 + 64 + lane;
-            tile[r][64 + lane] = (rowok && gx < W) ? grow[gx] : 0.0f;
+    // each wave owns tile rows wv, wv+4, ...; all global loads are issued before the first LDS store
+    // (a load -> store loop serialises six HBM round trips per workgroup)
+    {
+        constexpr int NR = (LROWS + 3) / 4; // 6
+        float v[NR], hv[NR];
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int r = wv + 4 * k;
+            const int gy = y0 + r;
+            const bool rowok = r < LROWS && gy >= 0 && gy < H;
+            const float *grow = g + (size_t)(rowok ? gy : 0) * W;
+            const int gx = x0 + lane, hx = x0 + 64 + lane;
+            v[k] = (rowok && gx >= 0 && gx < W) ? grow[gx] : 0.0f;
+            hv[k] = (rowok && lane < 2 * HALO && hx < W) ? grow[hx] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int r = wv + 4 * k;
+            if (r < LROWS) {
+                tile[r][lane] = v[k];
+                if (lane < 2 * HALO) tile[r][64 + lane] = hv[k];
+            }
         }
     }
     __syncthreads();

@@ -28,7 +28,7 @@
 namespace {
 
 constexpr int SEL_NT = 1024;
-constexpr int CNT_N1 = 0, CNT_N2 = 1, CNT_NACC = 2, CNT_N1_ORIG = 3, CNT_N2_ORIG = 4, CNT_PARITY = 5, CNT_WORDS = 8;
+constexpr int CNT_N1 = 0, CNT_N2 = 1, CNT_NACC = 2, CNT_N1_ORIG = 3, CNT_N2_ORIG = 4, CNT_PARITY = 5, CNT_FILLED = 6, CNT_WORDS = 8;
 
 struct PairWs {
     uint32_t *rowkey, *colkey, *rows0, *rows1, *cols0, *cols1; // no runtime-indexed arrays: they would live in scratch
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_match_init(uint32_t *ws, const int32_t 
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         p.cnt[CNT_N1] = n1; p.cnt[CNT_N2] = n2; p.cnt[CNT_NACC] = 0;
-        p.cnt[CNT_N1_ORIG] = n1; p.cnt[CNT_N2_ORIG] = n2; p.cnt[CNT_PARITY] = 0;
+        p.cnt[CNT_N1_ORIG] = n1; p.cnt[CNT_N2_ORIG] = n2; p.cnt[CNT_PARITY] = 0; p.cnt[CNT_FILLED] = 0;
         if (n1 > 0 && n2 == 0) atomicOr(status, (int)PGX_ST_EMPTY_SET); // KeypointMatching.cs:61
     }
 }
@@ -306,6 +306,58 @@ __host__ __device__ inline size_t tail_lds_words(int W)
     return (size_t)6 * TAIL_MAX + (size_t)2 * TAIL_MAX / 4 + 8 + (size_t)2 * TAIL_MAX * W;
 }
 
+// Wide fill of the tail's cached distance matrices: once an image pair's residual fits the tail
+// (<= TAIL_MAX rows and columns) every entry of D (and of its transpose) is computed exactly once by
+// the whole chip instead of by the pair's single tail workgroup.  One wavefront per matrix row, two
+// adjacent entries per lane (dword stores); side 0 writes D[i][j] and the row bests, side 1 the
+// transpose and the column bests (keys carry LOCAL indices = positions in the compacted lists and
+// go to rowkey/colkey, which the wide rounds no longer need for this pair).
+__global__ __launch_bounds__(256) void k_tail_fill(uint32_t *ws, const uint32_t *__restrict__ desc,
+                                                   const int32_t *__restrict__ pairlist, int S)
+{
+    const int side = blockIdx.y, m = blockIdx.z;
+    PairWs p = pair_ws(ws, m, S);
+    const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2], parity = p.cnt[CNT_PARITY];
+    if (n1 <= 0 || n2 <= 0 || n1 > TAIL_MAX || n2 > TAIL_MAX) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t *dX = desc + (size_t)pairlist[2 * m + side] * S * 8;
+    const uint32_t *dY = desc + (size_t)pairlist[2 * m + (side ^ 1)] * S * 8;
+    const uint32_t *xl = side ? (parity ? p.cols1 : p.cols0) : (parity ? p.rows1 : p.rows0);
+    const uint32_t *yl = side ? (parity ? p.rows1 : p.rows0) : (parity ? p.cols1 : p.cols0);
+    const int nx = side ? n2 : n1, ny = side ? n1 : n2;
+    const int ystride = (ny + 7) & ~7;
+    uint16_t *mat = p.dcache + (side ? (size_t)PGX_TAIL_MAX * PGX_TAIL_MAX : 0);
+    uint32_t *bestout = side ? p.colkey : p.rowkey;
+    const int i = blockIdx.x * 4 + wv;
+    if (i >= nx) return; // wave-uniform
+    const uint4 a0 = *reinterpret_cast<const uint4 *>(dX + (size_t)xl[i] * 8);
+    const uint4 a1 = *reinterpret_cast<const uint4 *>(dX + (size_t)xl[i] * 8 + 4);
+    uint32_t best = PGX_KEY_NONE;
+    for (int j2 = lane * 2; j2 < ystride; j2 += 128) {
+        uint32_t d0 = 0xFFFFu, d1 = 0xFFFFu;
+        if (j2 < ny) {
+            const uint32_t *b = dY + (size_t)yl[j2] * 8;
+            const uint4 b0 = *reinterpret_cast<const uint4 *>(b), b1 = *reinterpret_cast<const uint4 *>(b + 4);
+            d0 = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                 __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+            const uint32_t key = (d0 << PGX_IDX_BITS) | (uint32_t)j2;
+            best = key < best ? key : best;
+        }
+        if (j2 + 1 < ny) {
+            const uint32_t *b = dY + (size_t)yl[j2 + 1] * 8;
+            const uint4 b0 = *reinterpret_cast<const uint4 *>(b), b1 = *reinterpret_cast<const uint4 *>(b + 4);
+            d1 = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                 __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+            const uint32_t key = (d1 << PGX_IDX_BITS) | (uint32_t)(j2 + 1);
+            best = key < best ? key : best;
+        }
+        *reinterpret_cast<uint32_t *>(mat + (size_t)i * ystride + j2) = d0 | (d1 << 16);
+    }
+    best = wave_min_u32(best);
+    if (lane == 0) bestout[i] = best;
+    if (blockIdx.x == 0 && side == 0 && threadIdx.x == 0) p.cnt[CNT_FILLED] = 1;
+}
+
 template <int WORDS>
 __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict__ dA, const uint32_t *__restrict__ dB,
                                 int words_rt, uint32_t *lds, int *dbg)
@@ -372,8 +424,13 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
             if (lane == 0) bestout[i] = best;
         }
     };
-    fill(rdesc, R, cdesc, C, Cs, D, rbest);
-    fill(cdesc, C, rdesc, R, Rs, DT, cbest);
+    if (p.cnt[CNT_FILLED]) { // done by k_tail_fill on the whole chip; pick up the first bests
+        for (int i = tid; i < R; i += nth) rbest[i] = p.rowkey[i];
+        for (int j = tid; j < C; j += nth) cbest[j] = p.colkey[j];
+    } else {
+        fill(rdesc, R, cdesc, C, Cs, D, rbest);
+        fill(cdesc, C, rdesc, R, Rs, DT, cbest);
+    }
     if (tid == 0) { ctr[0] = 0; ctr[1] = 0; }
     __syncthreads();
 
@@ -585,6 +642,10 @@ void pgx_launch_match(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const
             hipLaunchKernelGGL(k_match_select, dim3(plan.M), dim3(SEL_NT), 0, s, ws, plan.stride,
                                reinterpret_cast<unsigned long long *>(status + 4) + (r < PGX_MAX_WIDE_ROUNDS ? r : PGX_MAX_WIDE_ROUNDS - 1));
         }
+    }
+    if (plan.words == 8) {
+        ProfScope ps(ctx, "tail_fill");
+        hipLaunchKernelGGL(k_tail_fill, dim3(PGX_TAIL_MAX / 4, 2, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
     }
     {
         ProfScope ps(ctx, "match_finish");

@@ -6,19 +6,23 @@
 //
 // Parallel formulation (checked against the literal oracle): priority =
 // (score desc, input index asc).  Round: every undecided point with no higher-priority
-// undecided point within r is accepted; every undecided point within r of an accepted one is
-// suppressed.  Output = accepted points in priority order.  On a 1080p frame with 1.3e5 raw
-// hits the undecided set shrinks ~2.6x per round (9 rounds).
+// undecided point within r is accepted (phase A); every undecided point within r of an accepted
+// one is suppressed (phase B).  Output = accepted points in priority order.  On a 1080p frame with
+// 1e5 raw hits the undecided set shrinks ~2.6x per round (9 rounds).
 //
 // Launch structure (all frames of a batch in every launch, blockIdx.y = frame):
-//   k_nms_count / k_nms_cellscan / k_nms_scatter   counting sort of the points into a uniform
-//        grid of cells >= r, all per-point arrays re-ordered into cell order so a neighbour
-//        scan reads three contiguous runs;
-//   WIDE_ROUNDS x k_nms_phase_cell<0>, <1>   one wavefront per cell, whole chip;
-//   k_nms_tail   one 1024-thread workgroup per frame: finishes the few points still undecided
-//        (rounds with an active list), then sorts the accepted points (bitonic, LDS) and
-//        writes the order.
-// Integer work on L2-resident data (a few MB per frame); latency-bound, not HBM-bound.
+//   k_nms_zero / k_nms_count / k_nms_cellscan / k_nms_scatter   counting sort of the points into a
+//        uniform grid of cells >= r; each point becomes one 16-byte record {xy, score, index, state}
+//        in cell order, so a 3x3-cell neighbourhood is three contiguous runs of records;
+//   WIDE_ROUNDS x (k_nms_phase<0>, k_nms_phase<1>)   one wavefront per cell, whole chip.  A per-cell
+//        count of undecided points lets finished cells leave after one load.
+//        phase A: lanes hold the neighbourhood in registers; the cell's undecided points are taken
+//                 one at a time (own cell first, then the rest) and a ballot decides "beaten";
+//        phase B: lanes hold the cell's own points; the few ACCEPTED neighbours are enumerated from
+//                 a ballot and broadcast one at a time;
+//   k_nms_tail   one 1024-thread workgroup per frame: finishes whatever is still undecided, then
+//        sorts the accepted points (bitonic, LDS) and writes the order.
+// Integer work on L2-resident data (a few MB per frame); latency/issue-bound, not HBM-bound.
 #include "pgx_internal.h"
 
 namespace {
@@ -29,8 +33,7 @@ constexpr uint32_t SORT_LDS_MAX = 16384; // u64 keys -> 128 KiB
 
 struct NmsLayout {
     int gw, gh, cs, ncell;
-    size_t off_cellstart, off_cellfill, off_sxy, off_sscore, off_sidx, off_state, off_listA, off_listB, off_accflag,
-        off_sortkeys, total;
+    size_t off_cellstart, off_cellfill, off_cellund, off_rec, off_listA, off_listB, off_accflag, off_sortkeys, total;
 };
 
 __host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_cap)
@@ -45,10 +48,8 @@ __host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     L.off_cellstart = take((size_t)(L.ncell + 1) * 4);
     L.off_cellfill = take((size_t)(L.ncell + 1) * 4);
-    L.off_sxy = take((size_t)n_cap * 4);
-    L.off_sscore = take((size_t)n_cap * 4);
-    L.off_sidx = take((size_t)n_cap * 4);
-    L.off_state = take((size_t)n_cap);
+    L.off_cellund = take((size_t)(L.ncell + 1) * 4);
+    L.off_rec = take((size_t)n_cap * 16);
     L.off_listA = take((size_t)n_cap * 4);
     L.off_listB = take((size_t)n_cap * 4);
     L.off_accflag = take((size_t)n_cap);
@@ -57,10 +58,11 @@ __host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_
     return L;
 }
 
+// rec = {x: y<<16|x, y: score, z: input index, w: state}
 struct NmsPtrs {
-    uint32_t *cell_start, *cell_fill, *s_xy, *s_idx, *listA, *listB;
-    int32_t *s_score;
-    uint8_t *state, *accflag;
+    uint32_t *cell_start, *cell_fill, *cell_und, *listA, *listB;
+    uint4 *rec;
+    uint8_t *accflag;
     unsigned long long *sortkeys;
 };
 
@@ -69,10 +71,8 @@ __device__ __forceinline__ NmsPtrs nms_ptrs(unsigned char *ws, const NmsLayout &
     NmsPtrs p;
     p.cell_start = reinterpret_cast<uint32_t *>(ws + L.off_cellstart);
     p.cell_fill = reinterpret_cast<uint32_t *>(ws + L.off_cellfill);
-    p.s_xy = reinterpret_cast<uint32_t *>(ws + L.off_sxy);
-    p.s_score = reinterpret_cast<int32_t *>(ws + L.off_sscore);
-    p.s_idx = reinterpret_cast<uint32_t *>(ws + L.off_sidx);
-    p.state = reinterpret_cast<uint8_t *>(ws + L.off_state);
+    p.cell_und = reinterpret_cast<uint32_t *>(ws + L.off_cellund);
+    p.rec = reinterpret_cast<uint4 *>(ws + L.off_rec);
     p.listA = reinterpret_cast<uint32_t *>(ws + L.off_listA);
     p.listB = reinterpret_cast<uint32_t *>(ws + L.off_listB);
     p.accflag = reinterpret_cast<uint8_t *>(ws + L.off_accflag);
@@ -80,12 +80,20 @@ __device__ __forceinline__ NmsPtrs nms_ptrs(unsigned char *ws, const NmsLayout &
     return p;
 }
 
+__device__ __forceinline__ uint32_t *rec_state(uint4 *rec, uint32_t p) { return reinterpret_cast<uint32_t *>(rec + p) + 3; }
+
 // 0 undecided, 1 accepted in the running round, 2 suppressed, 3 accepted earlier
-enum : uint8_t { ST_UNDECIDED = 0, ST_NEW = 1, ST_SUPPRESSED = 2, ST_ACCEPTED = 3 };
+enum : uint32_t { ST_UNDECIDED = 0, ST_NEW = 1, ST_SUPPRESSED = 2, ST_ACCEPTED = 3 };
 
 __device__ __forceinline__ bool better(int sq, uint32_t iq, int si, uint32_t ii)
 {
     return sq > si || (sq == si && iq < ii);
+}
+
+__device__ __forceinline__ bool within(uint32_t axy, uint32_t bxy, long long r2)
+{
+    const long long dx = (int)(axy & 0xFFFFu) - (int)(bxy & 0xFFFFu), dy = (int)(axy >> 16) - (int)(bxy >> 16);
+    return dx * dx + dy * dy <= r2;
 }
 
 __device__ __forceinline__ int clamp_n(const int32_t *n_raw_all, int f, int n_cap)
@@ -118,35 +126,31 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *excl, 
     return total;
 }
 
-__global__ __launch_bounds__(256) void k_nms_zero(int n_cap, int W, int H, int radius, unsigned char *ws_all, size_t ws_stride)
+__global__ __launch_bounds__(256) void k_nms_zero(NmsLayout L, unsigned char *ws_all, size_t ws_stride)
 {
-    const NmsLayout L = nms_layout(W, H, radius, n_cap);
     NmsPtrs P = nms_ptrs(ws_all + (size_t)blockIdx.y * ws_stride, L);
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c <= L.ncell) P.cell_fill[c] = 0;
 }
 
 __global__ __launch_bounds__(256) void k_nms_count(const uint32_t *__restrict__ raw_xy_all,
-                                                   const int32_t *__restrict__ n_raw_all, int n_cap, int W, int H,
-                                                   int radius, unsigned char *ws_all, size_t ws_stride)
+                                                   const int32_t *__restrict__ n_raw_all, int n_cap, NmsLayout L,
+                                                   unsigned char *ws_all, size_t ws_stride)
 {
     const int f = blockIdx.y;
     const int n = clamp_n(n_raw_all, f, n_cap);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const NmsLayout L = nms_layout(W, H, radius, n_cap);
     NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
     const uint32_t xy = raw_xy_all[(size_t)f * n_cap + i];
     const int cx = (int)(xy & 0xFFFFu) / L.cs, cy = (int)(xy >> 16) / L.cs;
     atomicAdd(&P.cell_fill[cy * L.gw + cx], 1u);
 }
 
-__global__ __launch_bounds__(NT) void k_nms_cellscan(int n_cap, int W, int H, int radius, unsigned char *ws_all,
-                                                     size_t ws_stride)
+__global__ __launch_bounds__(NT) void k_nms_cellscan(NmsLayout L, unsigned char *ws_all, size_t ws_stride)
 {
     __shared__ uint32_t wsum[NT / 64];
     const int f = blockIdx.x, tid = threadIdx.x;
-    const NmsLayout L = nms_layout(W, H, radius, n_cap);
     NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
     uint32_t carry = 0;
     for (int base = 0; base <= L.ncell; base += NT) {
@@ -155,180 +159,150 @@ __global__ __launch_bounds__(NT) void k_nms_cellscan(int n_cap, int W, int H, in
         uint32_t ex;
         const uint32_t tot = block_excl_scan(v, &ex, wsum);
         if (c <= L.ncell) P.cell_start[c] = carry + ex;
-        if (c < L.ncell) P.cell_fill[c] = carry + ex; // becomes the scatter cursor
+        if (c < L.ncell) { P.cell_fill[c] = carry + ex; P.cell_und[c] = v; } // scatter cursor; undecided = all
         carry += tot;
     }
 }
 
 __global__ __launch_bounds__(256) void k_nms_scatter(const uint32_t *__restrict__ raw_xy_all,
                                                      const int32_t *__restrict__ raw_score_all,
-                                                     const int32_t *__restrict__ n_raw_all, int n_cap, int W, int H,
-                                                     int radius, unsigned char *ws_all, size_t ws_stride)
+                                                     const int32_t *__restrict__ n_raw_all, int n_cap, NmsLayout L,
+                                                     unsigned char *ws_all, size_t ws_stride)
 {
     const int f = blockIdx.y;
     const int n = clamp_n(n_raw_all, f, n_cap);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const NmsLayout L = nms_layout(W, H, radius, n_cap);
     NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
     const uint32_t xy = raw_xy_all[(size_t)f * n_cap + i];
     const int cx = (int)(xy & 0xFFFFu) / L.cs, cy = (int)(xy >> 16) / L.cs;
     const uint32_t pos = atomicAdd(&P.cell_fill[cy * L.gw + cx], 1u);
-    P.s_xy[pos] = xy;
-    P.s_score[pos] = raw_score_all[(size_t)f * n_cap + i];
-    P.s_idx[pos] = (uint32_t)i;
-    P.state[pos] = ST_UNDECIDED;
+    P.rec[pos] = make_uint4(xy, (uint32_t)raw_score_all[(size_t)f * n_cap + i], (uint32_t)i, ST_UNDECIDED);
 }
 
-// phase A for one point: is there an undecided (at round start) better point within r?
-__device__ __forceinline__ bool point_beaten(const NmsPtrs &P, const NmsLayout &L, uint32_t p, long long r2)
+// The 3x3-cell neighbourhood of cell (cx, cy) as three runs of records, one flat index space.
+struct Runs { uint32_t q0, q1, q2, l0, l1, l2, total; };
+
+__device__ __forceinline__ Runs cell_runs(const NmsPtrs &P, const NmsLayout &L, int cx, int cy)
 {
-    const uint32_t xy = P.s_xy[p];
-    const int x = (int)(xy & 0xFFFFu), y = (int)(xy >> 16);
-    const int sc = P.s_score[p];
-    const uint32_t id = P.s_idx[p];
-    const int cx = x / L.cs, cy = y / L.cs;
+    Runs R;
     const int cx0 = cx > 0 ? cx - 1 : 0, cx1 = cx + 1 < L.gw ? cx + 1 : L.gw - 1;
-    const int cy0 = cy > 0 ? cy - 1 : 0, cy1 = cy + 1 < L.gh ? cy + 1 : L.gh - 1;
-    for (int yy = cy0; yy <= cy1; yy++) {
-        const uint32_t q0 = P.cell_start[yy * L.gw + cx0], q1 = P.cell_start[yy * L.gw + cx1 + 1];
-        for (uint32_t q = q0; q < q1; q++) {
-            const uint8_t stq = P.state[q];
-            if (stq != ST_UNDECIDED && stq != ST_NEW) continue; // NEW was undecided when the round began
-            if (q == p) continue;
-            const uint32_t qxy = P.s_xy[q];
-            const long long dx = (int)(qxy & 0xFFFFu) - x, dy = (int)(qxy >> 16) - y;
-            if (dx * dx + dy * dy > r2) continue;
-            if (better(P.s_score[q], P.s_idx[q], sc, id)) return true;
-        }
-    }
-    return false;
+    auto run = [&](int yy, uint32_t &q, uint32_t &len) {
+        if (yy < 0 || yy >= L.gh) { q = 0; len = 0; return; }
+        q = P.cell_start[yy * L.gw + cx0];
+        len = P.cell_start[yy * L.gw + cx1 + 1] - q;
+    };
+    run(cy - 1, R.q0, R.l0);
+    run(cy, R.q1, R.l1);
+    run(cy + 1, R.q2, R.l2);
+    R.total = R.l0 + R.l1 + R.l2;
+    return R;
 }
 
-// phase B for one undecided point: is an accepted point within r?
-__device__ __forceinline__ bool point_suppressed(const NmsPtrs &P, const NmsLayout &L, uint32_t p, long long r2)
+__device__ __forceinline__ uint32_t run_pos(const Runs &R, uint32_t fi)
 {
-    const uint32_t xy = P.s_xy[p];
-    const int x = (int)(xy & 0xFFFFu), y = (int)(xy >> 16);
-    const int cx = x / L.cs, cy = y / L.cs;
-    const int cx0 = cx > 0 ? cx - 1 : 0, cx1 = cx + 1 < L.gw ? cx + 1 : L.gw - 1;
-    const int cy0 = cy > 0 ? cy - 1 : 0, cy1 = cy + 1 < L.gh ? cy + 1 : L.gh - 1;
-    for (int yy = cy0; yy <= cy1; yy++) {
-        const uint32_t q0 = P.cell_start[yy * L.gw + cx0], q1 = P.cell_start[yy * L.gw + cx1 + 1];
-        for (uint32_t q = q0; q < q1; q++) {
-            const uint8_t stq = P.state[q];
-            if (stq != ST_NEW && stq != ST_ACCEPTED) continue;
-            const uint32_t qxy = P.s_xy[q];
-            const long long dx = (int)(qxy & 0xFFFFu) - x, dy = (int)(qxy >> 16) - y;
-            if (dx * dx + dy * dy <= r2) return true;
-        }
-    }
-    return false;
+    return fi < R.l0 ? R.q0 + fi : (fi < R.l0 + R.l1 ? R.q1 + (fi - R.l0) : R.q2 + (fi - R.l0 - R.l1));
 }
 
-// One wavefront per grid cell.  Lanes hold the 3x3-cell neighbourhood (three contiguous runs in
-// cell order) in registers, 64 x NB_REG neighbours per pass; the wave then walks the cell's own
-// undecided points one at a time -- every lane tests its neighbours against the broadcast centre
-// and a ballot decides -- so work is (undecided centres) x (neighbours / 64) wave-instructions with
-// all lanes busy, instead of (neighbours) x (centres / 64).
-// PHASE 0 = "is a better undecided point within r" (phase A), PHASE 1 = "is an accepted point
-// within r" (phase B, which also retires this cell's NEW marks to ACCEPTED).
-constexpr int NB_REG = 4;     // neighbour registers per lane and pass (256 neighbours)
-constexpr int CEN_MAX = 64;   // centre points staged per batch
+constexpr int NB_REG = 4; // neighbour records per lane and pass (256 neighbours)
 
+// PHASE 0 (A): accept the cell's undecided points that no better undecided point within r beats.
+// PHASE 1 (B): retire NEW -> ACCEPTED, suppress undecided points within r of an accepted one, recount.
 template <int PHASE>
-__global__ __launch_bounds__(256) void k_nms_phase_cell(const int32_t *__restrict__ n_raw_all, int n_cap, int W, int H,
-                                                        int radius, unsigned char *ws_all, size_t ws_stride)
+__global__ __launch_bounds__(256) void k_nms_phase(NmsLayout L, int radius, unsigned char *ws_all, size_t ws_stride)
 {
-    __shared__ uint32_t c_xy[4][CEN_MAX];
-    __shared__ int32_t c_score[4][CEN_MAX];
-    __shared__ uint32_t c_idx[4][CEN_MAX];
-    __shared__ uint32_t c_flag[4][CEN_MAX]; // bit0: undecided at entry, bit1: hit
+    __shared__ uint4 c_rec[4][64];
+    __shared__ uint32_t c_flag[4][64]; // 1 = undecided and not yet hit, 3 = hit
     const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (clamp_n(n_raw_all, f, n_cap) == 0) return;
-    const NmsLayout L = nms_layout(W, H, radius, n_cap);
     const int c = blockIdx.x * 4 + wv;
     if (c >= L.ncell) return; // wave-uniform
     NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
+    if (P.cell_und[c] == 0) return; // nothing left to decide here (also covers empty cells)
     const uint32_t p0 = P.cell_start[c], p1 = P.cell_start[c + 1];
-    if (p0 == p1) return;
     const long long r2 = (long long)radius * (long long)radius;
     const int cy = c / L.gw, cx = c - cy * L.gw;
-    const int cx0 = cx > 0 ? cx - 1 : 0, cx1 = cx + 1 < L.gw ? cx + 1 : L.gw - 1;
-    // the three neighbour runs (rows cy-1, cy, cy+1 of cells), as one flat index space
-    uint32_t rq[3], rlen[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int yy = cy - 1 + k;
-        if (yy < 0 || yy >= L.gh) { rq[k] = 0; rlen[k] = 0; continue; }
-        rq[k] = P.cell_start[yy * L.gw + cx0];
-        rlen[k] = P.cell_start[yy * L.gw + cx1 + 1] - rq[k];
-    }
-    const uint32_t ntot = rlen[0] + rlen[1] + rlen[2];
+    const Runs R = cell_runs(P, L, cx, cy);
+    uint32_t und_left = 0;
 
-    for (uint32_t pb = p0; pb < p1; pb += CEN_MAX) { // centre batches
+    for (uint32_t pb = p0; pb < p1; pb += 64) { // the cell's own points, 64 at a time
         const uint32_t p = pb + lane;
         const bool have = p < p1;
-        uint8_t st = have ? P.state[p] : (uint8_t)ST_SUPPRESSED;
-        if (PHASE == 1 && have && st == ST_NEW) { P.state[p] = ST_ACCEPTED; st = ST_ACCEPTED; }
-        const bool und = have && st == ST_UNDECIDED;
+        uint4 me = have ? P.rec[p] : make_uint4(0, 0, 0, ST_SUPPRESSED);
+        if (PHASE == 1 && me.w == ST_NEW) { *rec_state(P.rec, p) = ST_ACCEPTED; me.w = ST_ACCEPTED; }
+        const bool und = have && me.w == ST_UNDECIDED;
         if (!__any(und)) continue;
-        __builtin_amdgcn_wave_barrier();
-        c_flag[wv][lane] = und ? 1u : 0u;
-        if (und) {
-            c_xy[wv][lane] = P.s_xy[p];
-            if (PHASE == 0) { c_score[wv][lane] = P.s_score[p]; c_idx[wv][lane] = P.s_idx[p]; }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int ncen = (int)((p1 - pb < (uint32_t)CEN_MAX) ? p1 - pb : (uint32_t)CEN_MAX);
 
-        for (uint32_t nb0 = 0; nb0 < ntot; nb0 += 64 * NB_REG) { // neighbour passes
-            uint32_t nq[NB_REG], nxy[NB_REG], nid[NB_REG];
-            int32_t nsc[NB_REG];
-            bool nok[NB_REG];
-#pragma unroll
-            for (int k = 0; k < NB_REG; k++) {
-                const uint32_t fi = nb0 + k * 64 + lane;
-                bool ok = fi < ntot;
-                uint32_t q = 0;
-                if (ok) q = fi < rlen[0] ? rq[0] + fi : (fi < rlen[0] + rlen[1] ? rq[1] + (fi - rlen[0]) : rq[2] + (fi - rlen[0] - rlen[1]));
-                uint8_t sq = ok ? P.state[q] : (uint8_t)ST_SUPPRESSED;
-                if (PHASE == 0) ok = ok && (sq == ST_UNDECIDED || sq == ST_NEW); // NEW was undecided when the round began
-                else ok = ok && (sq == ST_NEW || sq == ST_ACCEPTED);
-                nq[k] = q;
-                nok[k] = ok;
-                nxy[k] = ok ? P.s_xy[q] : 0u;
-                if (PHASE == 0) { nsc[k] = ok ? P.s_score[q] : 0; nid[k] = ok ? P.s_idx[q] : 0u; }
-            }
-            const int nchunks = (int)(((ntot - nb0 < (uint32_t)(64 * NB_REG) ? ntot - nb0 : (uint32_t)(64 * NB_REG)) + 63) / 64);
-            for (int k = 0; k < ncen; k++) {
-                const uint32_t fl = c_flag[wv][k];
-                if (fl != 1u) continue; // decided, or already hit in an earlier pass (uniform)
-                const uint32_t cxy = c_xy[wv][k];
-                const int x = (int)(cxy & 0xFFFFu), y = (int)(cxy >> 16);
-                const int sc = PHASE == 0 ? c_score[wv][k] : 0;
-                const uint32_t id = PHASE == 0 ? c_idx[wv][k] : 0u;
-                bool hit = false;
-#pragma unroll
-                for (int j = 0; j < NB_REG; j++) {
-                    if (j >= nchunks) break; // uniform
-                    const long long dx = (int)(nxy[j] & 0xFFFFu) - x, dy = (int)(nxy[j] >> 16) - y;
-                    bool h = nok[j] && (dx * dx + dy * dy <= r2);
-                    if (PHASE == 0) h = h && nq[j] != pb + (uint32_t)k && better(nsc[j], nid[j], sc, id);
-                    hit = hit || h;
-                }
-                if (__any(hit)) { if (lane == 0) c_flag[wv][k] = 3u; }
-            }
+        if (PHASE == 0) {
+            // ---- own cell first: cheap and decides most points ----
             __builtin_amdgcn_wave_barrier();
+            c_rec[wv][lane] = me;
+            c_flag[wv][lane] = und ? 1u : 0u;
+            __builtin_amdgcn_wave_barrier();
+            const bool cand = have && (me.w == ST_UNDECIDED || me.w == ST_NEW); // NEW was undecided when the round began
+            unsigned long long alive = __ballot(und);
+            {
+                unsigned long long todo = alive;
+                while (todo) {
+                    const int k = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const uint4 ce = c_rec[wv][k];
+                    const bool h = cand && lane != k && within(me.x, ce.x, r2) && better((int)me.y, me.z, (int)ce.y, ce.z);
+                    if (__any(h)) alive &= ~(1ull << k);
+                }
+            }
+            // ---- then the whole neighbourhood, 256 records per pass, for the centres still standing ----
+            for (uint32_t nb0 = 0; nb0 < R.total && alive; nb0 += 64 * NB_REG) {
+                uint4 nb[NB_REG];
+                uint32_t nq[NB_REG];
+#pragma unroll
+                for (int k = 0; k < NB_REG; k++) {
+                    const uint32_t fi = nb0 + k * 64 + lane;
+                    nq[k] = fi < R.total ? run_pos(R, fi) : 0xFFFFFFFFu;
+                    nb[k] = fi < R.total ? P.rec[nq[k]] : make_uint4(0, 0, 0, ST_SUPPRESSED);
+                }
+                const int nch = (int)(((R.total - nb0 < (uint32_t)(64 * NB_REG) ? R.total - nb0 : (uint32_t)(64 * NB_REG)) + 63) / 64);
+                unsigned long long todo = alive;
+                while (todo) {
+                    const int k = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const uint4 ce = c_rec[wv][k];
+                    bool h = false;
+#pragma unroll
+                    for (int j = 0; j < NB_REG; j++) {
+                        if (j >= nch) break; // uniform
+                        h = h || ((nb[j].w == ST_UNDECIDED || nb[j].w == ST_NEW) && nq[j] != pb + (uint32_t)k &&
+                                  within(nb[j].x, ce.x, r2) && better((int)nb[j].y, nb[j].z, (int)ce.y, ce.z));
+                    }
+                    if (__any(h)) alive &= ~(1ull << k);
+                }
+            }
+            if (und && ((alive >> lane) & 1ull)) *rec_state(P.rec, p) = ST_NEW; // nobody better within r
+        } else {
+            // ---- enumerate the accepted neighbours (few) and broadcast them to the centre lanes ----
+            bool sup = false;
+            for (uint32_t nb0 = 0; nb0 < R.total; nb0 += 64 * NB_REG) {
+                uint4 nb[NB_REG];
+#pragma unroll
+                for (int k = 0; k < NB_REG; k++) {
+                    const uint32_t fi = nb0 + k * 64 + lane;
+                    nb[k] = fi < R.total ? P.rec[run_pos(R, fi)] : make_uint4(0, 0, 0, ST_SUPPRESSED);
+                }
+#pragma unroll
+                for (int k = 0; k < NB_REG; k++) {
+                    unsigned long long acc = __ballot(nb[k].w == ST_NEW || nb[k].w == ST_ACCEPTED);
+                    while (acc) {
+                        const int b = __builtin_ctzll(acc);
+                        acc &= acc - 1;
+                        const uint32_t axy = (uint32_t)__shfl((int)nb[k].x, b);
+                        sup = sup || within(me.x, axy, r2);
+                    }
+                }
+            }
+            if (und && sup) { *rec_state(P.rec, p) = ST_SUPPRESSED; me.w = ST_SUPPRESSED; }
+            und_left += (uint32_t)__popcll(__ballot(have && me.w == ST_UNDECIDED));
         }
-        // decisions of this batch
-        if (und) {
-            const bool hit = (c_flag[wv][lane] & 2u) != 0u;
-            if (PHASE == 0) { if (!hit) P.state[p] = ST_NEW; }
-            else { if (hit) P.state[p] = ST_SUPPRESSED; }
-        }
-        __builtin_amdgcn_wave_barrier();
     }
+    if (PHASE == 1 && lane == 0) P.cell_und[c] = und_left;
 }
 
 __device__ void bitonic_sort_u64(unsigned long long *keys, uint32_t n2p)
@@ -349,9 +323,37 @@ __device__ void bitonic_sort_u64(unsigned long long *keys, uint32_t n2p)
     __syncthreads();
 }
 
+// serial-per-thread neighbour walks for the few leftovers of the tail
+__device__ __forceinline__ bool tail_beaten(const NmsPtrs &P, const NmsLayout &L, uint32_t p, long long r2)
+{
+    const uint4 me = P.rec[p];
+    const int cx = (int)(me.x & 0xFFFFu) / L.cs, cy = (int)(me.x >> 16) / L.cs;
+    const Runs R = cell_runs(P, L, cx, cy);
+    for (uint32_t fi = 0; fi < R.total; fi++) {
+        const uint32_t q = run_pos(R, fi);
+        if (q == p) continue;
+        const uint4 o = P.rec[q];
+        if (o.w != ST_UNDECIDED && o.w != ST_NEW) continue;
+        if (within(o.x, me.x, r2) && better((int)o.y, o.z, (int)me.y, me.z)) return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ bool tail_suppressed(const NmsPtrs &P, const NmsLayout &L, uint32_t p, long long r2)
+{
+    const uint4 me = P.rec[p];
+    const int cx = (int)(me.x & 0xFFFFu) / L.cs, cy = (int)(me.x >> 16) / L.cs;
+    const Runs R = cell_runs(P, L, cx, cy);
+    for (uint32_t fi = 0; fi < R.total; fi++) {
+        const uint4 o = P.rec[run_pos(R, fi)];
+        if ((o.w == ST_NEW || o.w == ST_ACCEPTED) && within(o.x, me.x, r2)) return true;
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw_score_all,
-                                                 const int32_t *__restrict__ n_raw_all, int n_cap, int W, int H,
-                                                 int radius, int wide_done, unsigned char *ws_all, size_t ws_stride,
+                                                 const int32_t *__restrict__ n_raw_all, int n_cap, NmsLayout L,
+                                                 int radius, unsigned char *ws_all, size_t ws_stride,
                                                  uint32_t *__restrict__ order_all, int32_t *__restrict__ n_kept_all,
                                                  int kp_cap, int *status)
 {
@@ -363,7 +365,6 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
     const int n = clamp_n(n_raw_all, f, n_cap);
     const int32_t *raw_score = raw_score_all + (size_t)f * n_cap;
     uint32_t *order = order_all + (size_t)f * kp_cap;
-    const NmsLayout L = nms_layout(W, H, radius, n_cap);
     NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
     if (n == 0) {
         if (tid == 0) n_kept_all[f] = 0;
@@ -371,12 +372,15 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
     }
     const long long r2 = (long long)radius * (long long)radius;
 
-    if (radius >= 0 && wide_done) {
-        // ---- remaining rounds on an active list ----
+    if (radius >= 0) {
+        // ---- remaining rounds on an active list (normally empty after the wide rounds) ----
         if (tid == 0) sh_cnt = 0;
         __syncthreads();
-        for (int p = tid; p < n; p += NT)
-            if (P.state[p] == ST_UNDECIDED) P.listA[atomicAdd(&sh_cnt, 1u)] = (uint32_t)p;
+        for (int c = tid; c < L.ncell; c += NT) {
+            if (P.cell_und[c] == 0) continue;
+            for (uint32_t p = P.cell_start[c]; p < P.cell_start[c + 1]; p++)
+                if (P.rec[p].w == ST_UNDECIDED) P.listA[atomicAdd(&sh_cnt, 1u)] = p;
+        }
         __syncthreads();
         uint32_t *cur = P.listA, *nxt = P.listB;
         int n_act = (int)sh_cnt;
@@ -384,21 +388,21 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
         while (n_act > 0) {
             for (int a = tid; a < n_act; a += NT) {
                 const uint32_t p = cur[a];
-                if (!point_beaten(P, L, p, r2)) P.state[p] = ST_NEW;
+                if (!tail_beaten(P, L, p, r2)) *rec_state(P.rec, p) = ST_NEW;
             }
             __syncthreads();
             if (tid == 0) sh_cnt = 0;
             __syncthreads();
             for (int a = tid; a < n_act; a += NT) {
                 const uint32_t p = cur[a];
-                if (P.state[p] == ST_NEW) continue;
-                if (point_suppressed(P, L, p, r2)) P.state[p] = ST_SUPPRESSED;
+                if (P.rec[p].w == ST_NEW) continue;
+                if (tail_suppressed(P, L, p, r2)) *rec_state(P.rec, p) = ST_SUPPRESSED;
                 else nxt[atomicAdd(&sh_cnt, 1u)] = p; // order inside the list is irrelevant
             }
             __syncthreads();
             for (int a = tid; a < n_act; a += NT) {
                 const uint32_t p = cur[a];
-                if (P.state[p] == ST_NEW) P.state[p] = ST_ACCEPTED;
+                if (P.rec[p].w == ST_NEW) *rec_state(P.rec, p) = ST_ACCEPTED;
             }
             n_act = (int)sh_cnt;
             uint32_t *t = cur; cur = nxt; nxt = t;
@@ -411,10 +415,12 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
     if (tid == 0) sh_cnt = 0;
     __syncthreads();
     for (int p = tid; p < n; p += NT) {
-        const bool acc = all_accepted || P.state[p] == ST_ACCEPTED;
+        int sc;
+        uint32_t id;
+        bool acc;
+        if (all_accepted) { acc = true; sc = raw_score[p]; id = (uint32_t)p; }
+        else { const uint4 me = P.rec[p]; acc = me.w == ST_ACCEPTED; sc = (int)me.y; id = me.z; }
         if (acc) {
-            const int sc = all_accepted ? raw_score[p] : P.s_score[p];
-            const uint32_t id = all_accepted ? (uint32_t)p : P.s_idx[p];
             const uint32_t inv = ~((uint32_t)sc ^ 0x80000000u); // larger score -> smaller key
             P.sortkeys[atomicAdd(&sh_cnt, 1u)] = ((unsigned long long)inv << 32) | id;
         }
@@ -480,14 +486,13 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
     const dim3 pgrid((n_cap + 255) / 256, F);
     const dim3 cgrid((L.ncell + 3) / 4, F);
     if (rounds) {
-        hipLaunchKernelGGL(k_nms_zero, dim3((L.ncell + 256) / 256, F), dim3(256), 0, s, n_cap, W, H, radius, ws, ws_stride);
-        hipLaunchKernelGGL(k_nms_count, pgrid, dim3(256), 0, s, raw_xy, n_raw, n_cap, W, H, radius, ws, ws_stride);
-        hipLaunchKernelGGL(k_nms_cellscan, dim3(F), dim3(NT), 0, s, n_cap, W, H, radius, ws, ws_stride);
-        hipLaunchKernelGGL(k_nms_scatter, pgrid, dim3(256), 0, s, raw_xy, raw_score, n_raw, n_cap, W, H, radius, ws,
-                           ws_stride);
+        hipLaunchKernelGGL(k_nms_zero, dim3((L.ncell + 256) / 256, F), dim3(256), 0, s, L, ws, ws_stride);
+        hipLaunchKernelGGL(k_nms_count, pgrid, dim3(256), 0, s, raw_xy, n_raw, n_cap, L, ws, ws_stride);
+        hipLaunchKernelGGL(k_nms_cellscan, dim3(F), dim3(NT), 0, s, L, ws, ws_stride);
+        hipLaunchKernelGGL(k_nms_scatter, pgrid, dim3(256), 0, s, raw_xy, raw_score, n_raw, n_cap, L, ws, ws_stride);
         for (int r = 0; r < WIDE_ROUNDS; r++) {
-            hipLaunchKernelGGL(k_nms_phase_cell<0>, cgrid, dim3(256), 0, s, n_raw, n_cap, W, H, radius, ws, ws_stride);
-            hipLaunchKernelGGL(k_nms_phase_cell<1>, cgrid, dim3(256), 0, s, n_raw, n_cap, W, H, radius, ws, ws_stride);
+            hipLaunchKernelGGL(k_nms_phase<0>, cgrid, dim3(256), 0, s, L, radius, ws, ws_stride);
+            hipLaunchKernelGGL(k_nms_phase<1>, cgrid, dim3(256), 0, s, L, radius, ws, ws_stride);
         }
     }
     static bool attr_set = false;
@@ -496,6 +501,6 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
                                   (int)(SORT_LDS_MAX * 8));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_nms_tail, dim3(F), dim3(NT), SORT_LDS_MAX * 8, s, raw_score, n_raw, n_cap, W, H, radius,
-                       rounds ? 1 : 0, ws, ws_stride, order, n_kept, kp_cap, status);
+    hipLaunchKernelGGL(k_nms_tail, dim3(F), dim3(NT), SORT_LDS_MAX * 8, s, raw_score, n_raw, n_cap, L, radius, ws,
+                       ws_stride, order, n_kept, kp_cap, status);
 }
