@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgx.so")
+LIB_PATH = os.environ.get("PGX_LIB", os.path.join(_HERE, "libpgx.so"))  # PGX_LIB: developer A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 
 PGX_OK = 0
