@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[1]): 1920x1080 RGBA64 frame pairs, dewarp -> gra
 detect -> NMS (r=16) -> BRIEF-256 -> all-pairs Hamming match with the reference's greedy
 assignment, 4096 keypoints per frame (lists truncated to their first 4096 in NMS order: a harness
 choice, the reference has no cap).  One "step" = one batch of B independent image pairs per GPU
-(--pairs-per-step, default 8), frames already resident in HBM; value = sum over pairs of N1*N2
+(--pairs-per-step, default 32), frames already resident in HBM; value = sum over pairs of N1*N2
 divided by the WHOLE step time (detect + match), max over ranks.  Weak scaling: every rank
 processes its own B pairs; the per-pair match lists are all-gathered (RCCL) once after the timed
 region's last step -- they are the input of the (host-side) track graph.
@@ -44,11 +44,14 @@ def log(*a):
 
 
 def make_inputs(pairs_per_step, rank, cache_dir="/tmp/pgx_bench_cache"):
+    """2B frames: pair p = (base frame p mod NB, the same frame translated by a pair-specific offset), NB = min(B, 8)
+    seeded base frames per rank.  Every frame of the batch is a different image."""
     from photogrammetry_amd import synth
     os.makedirs(cache_dir, exist_ok=True)
-    frames = []
-    for p in range(pairs_per_step):
-        seed = 1234 + 1000 * rank + p
+    nb = min(pairs_per_step, 8)
+    bases = []
+    for b in range(nb):
+        seed = 1234 + 1000 * rank + b
         path = os.path.join(cache_dir, "frame_%dx%d_%d.npy" % (W, H, seed))
         if os.path.exists(path):
             f0 = np.load(path)
@@ -58,8 +61,13 @@ def make_inputs(pairs_per_step, rank, cache_dir="/tmp/pgx_bench_cache"):
                 np.save(path, f0)
             except OSError:
                 pass
-        frames.append(f0)
-        frames.append(synth.shift_frame(f0, 37, 11))
+        bases.append(f0)
+    frames = []
+    for p in range(pairs_per_step):
+        k = p // nb
+        base = bases[p % nb] if k == 0 else synth.shift_frame(bases[p % nb], -13 * k, 7 * k)
+        frames.append(base)
+        frames.append(synth.shift_frame(base, 37 + 5 * k, 11 + 3 * k))
     return np.stack(frames)  # [2B][H][W][4]
 
 
@@ -91,8 +99,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-step", type=int, default=8)
-    ap.add_argument("--cpu-sample", type=int, default=1536)
+    ap.add_argument("--pairs-per-step", type=int, default=32)
+    ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dewarp", action="store_true")
     args = ap.parse_args()
@@ -191,34 +199,51 @@ def main():
         step_ms = dt_max / args.steps * 1e3
         match_ms = sum(kern[k]["ms_per_step"] for k in ("match_init", "ham_argmin", "match_select", "tail_fill", "match_finish") if k in kern)
         detect_ms = sum(kern[k]["ms_per_step"] for k in ("dewarp_gray", "fast", "nms", "brief") if k in kern)
-        dominant = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
         npix = W * H
-        roof = None
-        if dominant == "ham_argmin":
-            ops = evals * 2.0 * P                                  # algorithmic int8 ops issued per step
-            ach = ops / (kern["ham_argmin"]["ms_per_step"] * 1e-3)
-            roof = {"kernel": "ham_argmin", "bound": "mfma", "achieved": ach / 1e12, "peak": I8_MFMA_PEAK_OPS / 1e12,
-                    "unit": "TOP/s", "frac": ach / I8_MFMA_PEAK_OPS, "traffic": None,
-                    "algorithmic": "2*P=512 int8 ops per descriptor-pair evaluation x %d evaluations per step "
-                                   "(%d launches)" % (evals, rounds_wide)}
-        elif dominant in ("dewarp_gray", "fast"):
-            per_px = 20.0 if dominant == "dewarp_gray" else 4.0
-            if dominant == "dewarp_gray" and dmap is None:
-                per_px = 12.0
-            byts = per_px * npix * F
-            ach = byts / (kern[dominant]["ms_per_step"] * 1e-3)
-            roof = {"kernel": dominant, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK, "traffic": None,
-                    "algorithmic": "%.0f B/pixel x %d pixels x %d frames per launch" % (per_px, npix, F)}
-        elif dominant is not None:
-            # integer / latency-bound stages (NMS rounds, in-workgroup finish): price them against the
-            # detect stream they sit beside: 24 B/pixel of the whole detect chain
+        n_raw_tot = float(nraw.sum())
+        n_kept_tot = float(n_used.sum())
+
+        def hbm(name, byts, what):
+            t = kern[name]["ms_per_step"] * 1e-3
+            return {"kernel": name, "bound": "hbm", "achieved": byts / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": byts / t / HBM_PEAK, "traffic": traffic.get(name), "algorithmic": what}
+
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")   # HBM bytes per frame from separate rocprofv3 --pmc passes
+        if os.path.exists(tpath):
+            for k, v in json.load(open(tpath)).get("bytes_per_frame", {}).items():
+                traffic[k] = v * F
+        rooflines = {}
+        if "dewarp_gray" in kern:
+            per_px = 12.0 if dmap is None else 20.0
+            rooflines["dewarp_gray"] = hbm("dewarp_gray", per_px * npix * F,
+                                           "%.0f B/pixel (8 map + 8 gathered source + 4 grey) x %d px x %d frames per launch" % (per_px, npix, F))
+        if "fast" in kern:
+            rooflines["fast"] = hbm("fast", 4.5 * npix * F + 16.0 * n_raw_tot,
+                                    "4 B/px grey read + 0.5 B/px ballot planes + 16 B per raw hit, %d frames (3 launches)" % F)
+        if "nms" in kern:
+            rooflines["nms"] = hbm("nms", 8.0 * n_raw_tot + 4.0 * n_kept_tot,
+                                   "integer/latency-bound stage on L2-resident lists: 8 B per raw hit in + 4 B per survivor out "
+                                   "(%d raw hits, %d survivors per step)" % (n_raw_tot, n_kept_tot))
+        if "brief" in kern:
+            rooflines["brief"] = hbm("brief", (2.0 * P * 4 + 48.0) * n_kept_tot,
+                                     "L2-latency-bound gathers: 2*P*4 B gathered + 48 B written per survivor")
+        if "ham_argmin" in kern:
+            ops = evals * 2.0 * P
+            t = kern["ham_argmin"]["ms_per_step"] * 1e-3
+            rooflines["ham_argmin"] = {"kernel": "ham_argmin", "bound": "mfma", "achieved": ops / t / 1e12,
+                                       "peak": I8_MFMA_PEAK_OPS / 1e12, "unit": "TOP/s", "frac": ops / t / I8_MFMA_PEAK_OPS,
+                                       "traffic": None,
+                                       "algorithmic": "2*P = 512 int8 ops per descriptor-pair evaluation x %d evaluations "
+                                                      "per step over %d launches" % (evals, rounds_wide)}
+        if detect_ms:
             byts = 24.0 * npix * F
-            ach = byts / (kern[dominant]["ms_per_step"] * 1e-3)
-            roof = {"kernel": dominant, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK, "traffic": None,
-                    "algorithmic": "latency-bound integer stage; priced as the detect chain's 24 B/pixel x %d frames "
-                                   "over this kernel's time" % F}
+            rooflines["detect_chain"] = {"kernel": "dewarp_gray+fast+nms+brief", "bound": "hbm",
+                                         "achieved": byts / (detect_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                         "frac": byts / (detect_ms * 1e-3) / HBM_PEAK, "traffic": None,
+                                         "algorithmic": "SURVEY 8d: 24 B/pixel for the fused-minimum detect stream x %d frames" % F}
+        dominant = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
+        roof = rooflines.get(dominant)
         result = {
             "metric": "descriptor pairs matched/sec", "value": job_pairs_per_step * args.steps / dt_max,
             "unit": "descriptor pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,6 +257,7 @@ def main():
                        "pairs_per_step_per_gpu": B, "keypoints": [int(x) for x in n_used.tolist()],
                        "raw_hits": [int(x) for x in nraw.tolist()], "parallelism": "pair-sharded x%d" % world},
             "roofline": roof,
+            "rooflines": rooflines,
             "kernels": kern,
             "detect": {"ms_per_step": detect_ms, "frames_per_s": F / (detect_ms * 1e-3) if detect_ms else None},
             "match_only": {"ms_per_step": match_ms,

@@ -483,11 +483,9 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
     while (true) {
         const int nrd = (int)ctr[0], ncd = (int)ctr[1];
         if (tid == 0) { atomicAdd(&dbg[3], 1); atomicAdd(&dbg[4], nrd); atomicAdd(&dbg[5], ncd); }
-        const unsigned long long tq0 = wall_clock64();
         scan_rows4(D, Cs, C, calive, rdl, nrd, rbest);
         scan_rows4(DT, Rs, R, ralive, cdl, ncd, cbest);
         __syncthreads();
-        const unsigned long long tq1 = wall_clock64();
         if (tid == 0) { ctr[0] = 0; ctr[1] = 0; ctr[3] = 0; ctr[4] = 0; }
         // accept mutual edges (every alive row points at an alive column here)
         for (int i = tid; i < R; i += nth) {
@@ -516,7 +514,6 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
             if (!ralive[cbest[j] & PGX_IDX_MASK]) cdl[atomicAdd(&ctr[1], 1u)] = (uint32_t)j;
         }
         __syncthreads();
-        if (tid == 0) { atomicAdd(&dbg[6], (int)(tq1 - tq0)); atomicAdd(&dbg[7], (int)(wall_clock64() - tq1)); }
         if (ctr[3] == 0 || ctr[4] == 0) break; // uniform
     }
     if (tid == 0) {
