@@ -10,18 +10,18 @@
 //   so score = longest circular run of zero bits of S if that is >= 12, else none.
 //
 // HBM-bound: 4 B/px grey read (+ 0.5 B/px of ballot planes written).  Three launches:
-//   k_fast_planes   64x16-pixel tiles staged through LDS (halo 3); one wave per 4 tile rows,
+//   k_fast_planes   64x32-pixel tiles staged through LDS (halo 3); one wave per 8 tile rows,
 //                   one lane per pixel; per 64-pixel row segment three 64-bit ballots of the
 //                   score bits + the count -> seg[F][H][ntx][4]
 //   k_seg_scan      one workgroup per frame: exclusive scan of the counts in (y, tx) order
 //                   = raster order; n_raw[f]
-//   k_fast_compact  one wave per segment: rank = popcount(mask below lane) -> raw_xy/raw_score
+//   k_fast_compact  one thread per segment walks its set bits in x order -> raw_xy/raw_score
 #include "pgx_internal.h"
 
 namespace {
 
-constexpr int TW = 64, TH = 16, HALO = 3;
-constexpr int LROWS = TH + 2 * HALO;  // 22
+constexpr int TW = 64, TH = 32, HALO = 3;
+constexpr int LROWS = TH + 2 * HALO;  // 38
 constexpr int LSTRIDE = 72;           // >= 70, keeps rows 16-B aligned
 
 __global__ __launch_bounds__(256) void k_fast_planes(const float *__restrict__ gray, int W, int H, float T,
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_fast_planes(const float *__restrict__ g
     // each wave owns tile rows wv, wv+4, ...; all global loads are issued before the first LDS store
     // (a load -> store loop serialises six HBM round trips per workgroup)
     {
-        constexpr int NR = (LROWS + 3) / 4; // 6
+        constexpr int NR = (LROWS + 3) / 4; // 10
         float v[NR], hv[NR];
 #pragma unroll
         for (int k = 0; k < NR; k++) {
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void k_fast_planes(const float *__restrict__ g
 
     const int x = tx * TW + lane;
 #pragma unroll 1
-    for (int k = 0; k < 4; k++) {
-        const int ry = wv * 4 + k;
+    for (int k = 0; k < TH / 4; k++) {
+        const int ry = wv * (TH / 4) + k;
         const int y = ty * TH + ry;
         if (y >= H) break; // wave-uniform
         int score = 0;
@@ -163,6 +163,8 @@ __global__ __launch_bounds__(1024) void k_seg_scan(const unsigned long long *__r
     }
 }
 
+// one THREAD per 64-pixel segment (segments hold ~3 hits on average: a wave per segment would be 2M
+// nearly empty waves per 64-frame batch); the thread walks the set bits of its segment in x order
 __global__ __launch_bounds__(256) void k_fast_compact(const unsigned long long *__restrict__ seg,
                                                       const uint32_t *__restrict__ segoff, int H, int ntx,
                                                       uint32_t *__restrict__ raw_xy, int32_t *__restrict__ raw_score,
@@ -170,21 +172,24 @@ __global__ __launch_bounds__(256) void k_fast_compact(const unsigned long long *
 {
     const int f = blockIdx.y;
     const int nseg = H * ntx;
-    const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= nseg) return;
     const unsigned long long *sg = seg + ((size_t)f * nseg + s) * 4;
-    const unsigned long long b0 = sg[0], b1 = sg[1], b2 = sg[2];
-    const unsigned long long any = b0 | b1 | b2;
-    if (!((any >> lane) & 1ull)) return;
-    const uint32_t base = segoff[(size_t)f * nseg + s];
-    const uint32_t pos = base + (uint32_t)__popcll(any & ((1ull << lane) - 1ull));
-    if (pos >= (uint32_t)raw_cap) return;
+    const ulonglong2 p01 = *reinterpret_cast<const ulonglong2 *>(sg);
+    const unsigned long long b0 = p01.x, b1 = p01.y, b2 = sg[2];
+    unsigned long long any = b0 | b1 | b2;
+    if (!any) return;
+    uint32_t pos = segoff[(size_t)f * nseg + s];
     const int y = s / ntx, tx = s - y * ntx;
-    const int x = tx * 64 + lane;
-    const int code = (int)((b0 >> lane) & 1ull) | ((int)((b1 >> lane) & 1ull) << 1) | ((int)((b2 >> lane) & 1ull) << 2);
-    raw_xy[(size_t)f * raw_cap + pos] = ((uint32_t)y << 16) | (uint32_t)x;
-    raw_score[(size_t)f * raw_cap + pos] = code + 11;
+    while (any) {
+        const int l = __builtin_ctzll(any);
+        any &= any - 1;
+        if (pos >= (uint32_t)raw_cap) break;
+        const int code = (int)((b0 >> l) & 1ull) | ((int)((b1 >> l) & 1ull) << 1) | ((int)((b2 >> l) & 1ull) << 2);
+        raw_xy[(size_t)f * raw_cap + pos] = ((uint32_t)y << 16) | (uint32_t)(tx * 64 + l);
+        raw_score[(size_t)f * raw_cap + pos] = code + 11;
+        pos++;
+    }
 }
 
 } // namespace
@@ -200,6 +205,6 @@ void pgx_launch_fast(hipStream_t s, const float *gray, int F, int W, int H, floa
     const int nseg = H * ntx;
     hipLaunchKernelGGL(k_fast_planes, dim3(ntx, nty, F), dim3(256), 0, s, gray, W, H, T, seg, ntx);
     hipLaunchKernelGGL(k_seg_scan, dim3(F), dim3(1024), 0, s, seg, nseg, segoff, n_raw, raw_cap, status);
-    hipLaunchKernelGGL(k_fast_compact, dim3((nseg + 3) / 4, F), dim3(256), 0, s, seg, segoff, H, ntx, raw_xy,
+    hipLaunchKernelGGL(k_fast_compact, dim3((nseg + 255) / 256, F), dim3(256), 0, s, seg, segoff, H, ntx, raw_xy,
                        raw_score, raw_cap);
 }

@@ -14,12 +14,12 @@
 //   k_nms_zero / k_nms_count / k_nms_cellscan / k_nms_scatter   counting sort of the points into a
 //        uniform grid of cells >= r; each point becomes one 16-byte record {xy, score, index, state}
 //        in cell order, so a 3x3-cell neighbourhood is three contiguous runs of records;
-//   WIDE_ROUNDS x (k_nms_phase<0>, k_nms_phase<1>)   one wavefront per cell, whole chip.  A per-cell
-//        count of undecided points lets finished cells leave after one load.
-//        phase A: lanes hold the neighbourhood in registers; the cell's undecided points are taken
-//                 one at a time (own cell first, then the rest) and a ballot decides "beaten";
-//        phase B: lanes hold the cell's own points; the few ACCEPTED neighbours are enumerated from
-//                 a ballot and broadcast one at a time;
+//   WIDE_ROUNDS x (k_nms_phase_a, k_nms_push), whole chip.
+//        phase A: one wavefront per cell that still has undecided points; lanes hold the neighbourhood
+//                 in registers, the cell's undecided points are taken one at a time (own cell first,
+//                 then the rest) and a ballot decides "beaten"; survivors are accepted and queued;
+//        phase B: one wavefront per NEWLY accepted point (a few thousand per frame in total): lanes =
+//                 its neighbours, every undecided one within r is suppressed; emits the sort key;
 //   k_nms_tail   one 1024-thread workgroup per frame: finishes whatever is still undecided, then
 //        sorts the accepted points (bitonic, LDS) and writes the order.
 // Integer work on L2-resident data (a few MB per frame); latency/issue-bound, not HBM-bound.
@@ -33,7 +33,7 @@ constexpr uint32_t SORT_LDS_MAX = 16384; // u64 keys -> 128 KiB
 
 struct NmsLayout {
     int gw, gh, cs, ncell;
-    size_t off_cellstart, off_cellfill, off_cellund, off_rec, off_listA, off_listB, off_accflag, off_sortkeys, total;
+    size_t off_cellstart, off_cellfill, off_cellund, off_counters, off_rec, off_listA, off_listB, off_accflag, off_sortkeys, total;
 };
 
 __host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_cap)
@@ -49,6 +49,7 @@ __host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_
     L.off_cellstart = take((size_t)(L.ncell + 1) * 4);
     L.off_cellfill = take((size_t)(L.ncell + 1) * 4);
     L.off_cellund = take((size_t)(L.ncell + 1) * 4);
+    L.off_counters = take(64);
     L.off_rec = take((size_t)n_cap * 16);
     L.off_listA = take((size_t)n_cap * 4);
     L.off_listB = take((size_t)n_cap * 4);
@@ -61,6 +62,7 @@ __host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_
 // rec = {x: y<<16|x, y: score, z: input index, w: state}
 struct NmsPtrs {
     uint32_t *cell_start, *cell_fill, *cell_und, *listA, *listB;
+    uint32_t *counters; // [0],[1] newly accepted this round (by round parity), [2] accepted so far (sort keys)
     uint4 *rec;
     uint8_t *accflag;
     unsigned long long *sortkeys;
@@ -72,6 +74,7 @@ __device__ __forceinline__ NmsPtrs nms_ptrs(unsigned char *ws, const NmsLayout &
     p.cell_start = reinterpret_cast<uint32_t *>(ws + L.off_cellstart);
     p.cell_fill = reinterpret_cast<uint32_t *>(ws + L.off_cellfill);
     p.cell_und = reinterpret_cast<uint32_t *>(ws + L.off_cellund);
+    p.counters = reinterpret_cast<uint32_t *>(ws + L.off_counters);
     p.rec = reinterpret_cast<uint4 *>(ws + L.off_rec);
     p.listA = reinterpret_cast<uint32_t *>(ws + L.off_listA);
     p.listB = reinterpret_cast<uint32_t *>(ws + L.off_listB);
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(256) void k_nms_zero(NmsLayout L, unsigned char *ws
     NmsPtrs P = nms_ptrs(ws_all + (size_t)blockIdx.y * ws_stride, L);
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c <= L.ncell) P.cell_fill[c] = 0;
+    if (c < 16) P.counters[c] = 0;
 }
 
 __global__ __launch_bounds__(256) void k_nms_count(const uint32_t *__restrict__ raw_xy_all,
@@ -206,13 +210,18 @@ __device__ __forceinline__ uint32_t run_pos(const Runs &R, uint32_t fi)
 
 constexpr int NB_REG = 4; // neighbour records per lane and pass (256 neighbours)
 
-// PHASE 0 (A): accept the cell's undecided points that no better undecided point within r beats.
-// PHASE 1 (B): retire NEW -> ACCEPTED, suppress undecided points within r of an accepted one, recount.
-template <int PHASE>
-__global__ __launch_bounds__(256) void k_nms_phase(NmsLayout L, int radius, unsigned char *ws_all, size_t ws_stride)
+__device__ __forceinline__ unsigned long long sort_key(int score, uint32_t idx)
+{
+    const uint32_t inv = ~((uint32_t)score ^ 0x80000000u); // larger score -> smaller key
+    return ((unsigned long long)inv << 32) | idx;
+}
+
+// Phase A, one wavefront per cell: accept the cell's undecided points that no better undecided
+// point within r beats, and append them to this round's "new" list.
+__global__ __launch_bounds__(256) void k_nms_phase_a(NmsLayout L, int radius, int round, unsigned char *ws_all,
+                                                     size_t ws_stride)
 {
     __shared__ uint4 c_rec[4][64];
-    __shared__ uint32_t c_flag[4][64]; // 1 = undecided and not yet hit, 3 = hit
     const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + wv;
     if (c >= L.ncell) return; // wave-uniform
@@ -221,88 +230,107 @@ __global__ __launch_bounds__(256) void k_nms_phase(NmsLayout L, int radius, unsi
     const uint32_t p0 = P.cell_start[c], p1 = P.cell_start[c + 1];
     const long long r2 = (long long)radius * (long long)radius;
     const int cy = c / L.gw, cx = c - cy * L.gw;
-    const Runs R = cell_runs(P, L, cx, cy);
-    uint32_t und_left = 0;
+    uint32_t und_seen = 0;
+    bool runs_ready = false;
+    Runs R;
 
     for (uint32_t pb = p0; pb < p1; pb += 64) { // the cell's own points, 64 at a time
         const uint32_t p = pb + lane;
         const bool have = p < p1;
-        uint4 me = have ? P.rec[p] : make_uint4(0, 0, 0, ST_SUPPRESSED);
-        if (PHASE == 1 && me.w == ST_NEW) { *rec_state(P.rec, p) = ST_ACCEPTED; me.w = ST_ACCEPTED; }
+        const uint4 me = have ? P.rec[p] : make_uint4(0, 0, 0, ST_SUPPRESSED);
         const bool und = have && me.w == ST_UNDECIDED;
-        if (!__any(und)) continue;
-
-        if (PHASE == 0) {
-            // ---- own cell first: cheap and decides most points ----
-            __builtin_amdgcn_wave_barrier();
-            c_rec[wv][lane] = me;
-            c_flag[wv][lane] = und ? 1u : 0u;
-            __builtin_amdgcn_wave_barrier();
-            const bool cand = have && (me.w == ST_UNDECIDED || me.w == ST_NEW); // NEW was undecided when the round began
-            unsigned long long alive = __ballot(und);
-            {
-                unsigned long long todo = alive;
-                while (todo) {
-                    const int k = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const uint4 ce = c_rec[wv][k];
-                    const bool h = cand && lane != k && within(me.x, ce.x, r2) && better((int)me.y, me.z, (int)ce.y, ce.z);
-                    if (__any(h)) alive &= ~(1ull << k);
-                }
+        unsigned long long alive = __ballot(und);
+        if (!alive) continue;
+        und_seen += (uint32_t)__popcll(alive);
+        if (!runs_ready) { R = cell_runs(P, L, cx, cy); runs_ready = true; }
+        // ---- own cell first: cheap and decides most points ----
+        __builtin_amdgcn_wave_barrier();
+        c_rec[wv][lane] = me;
+        __builtin_amdgcn_wave_barrier();
+        {
+            unsigned long long todo = alive;
+            while (todo) {
+                const int k = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint4 ce = c_rec[wv][k];
+                const bool h = und && lane != k && within(me.x, ce.x, r2) && better((int)me.y, me.z, (int)ce.y, ce.z);
+                if (__any(h)) alive &= ~(1ull << k);
             }
-            // ---- then the whole neighbourhood, 256 records per pass, for the centres still standing ----
-            for (uint32_t nb0 = 0; nb0 < R.total && alive; nb0 += 64 * NB_REG) {
-                uint4 nb[NB_REG];
-                uint32_t nq[NB_REG];
+        }
+        // ---- then the whole neighbourhood, 256 records per pass, for the centres still standing ----
+        for (uint32_t nb0 = 0; nb0 < R.total && alive; nb0 += 64 * NB_REG) {
+            uint4 nb[NB_REG];
+            uint32_t nq[NB_REG];
 #pragma unroll
-                for (int k = 0; k < NB_REG; k++) {
-                    const uint32_t fi = nb0 + k * 64 + lane;
-                    nq[k] = fi < R.total ? run_pos(R, fi) : 0xFFFFFFFFu;
-                    nb[k] = fi < R.total ? P.rec[nq[k]] : make_uint4(0, 0, 0, ST_SUPPRESSED);
-                }
-                const int nch = (int)(((R.total - nb0 < (uint32_t)(64 * NB_REG) ? R.total - nb0 : (uint32_t)(64 * NB_REG)) + 63) / 64);
-                unsigned long long todo = alive;
-                while (todo) {
-                    const int k = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const uint4 ce = c_rec[wv][k];
-                    bool h = false;
-#pragma unroll
-                    for (int j = 0; j < NB_REG; j++) {
-                        if (j >= nch) break; // uniform
-                        h = h || ((nb[j].w == ST_UNDECIDED || nb[j].w == ST_NEW) && nq[j] != pb + (uint32_t)k &&
-                                  within(nb[j].x, ce.x, r2) && better((int)nb[j].y, nb[j].z, (int)ce.y, ce.z));
-                    }
-                    if (__any(h)) alive &= ~(1ull << k);
-                }
+            for (int k = 0; k < NB_REG; k++) {
+                const uint32_t fi = nb0 + k * 64 + lane;
+                nq[k] = fi < R.total ? run_pos(R, fi) : 0xFFFFFFFFu;
+                nb[k] = fi < R.total ? P.rec[nq[k]] : make_uint4(0, 0, 0, ST_SUPPRESSED);
             }
-            if (und && ((alive >> lane) & 1ull)) *rec_state(P.rec, p) = ST_NEW; // nobody better within r
-        } else {
-            // ---- enumerate the accepted neighbours (few) and broadcast them to the centre lanes ----
-            bool sup = false;
-            for (uint32_t nb0 = 0; nb0 < R.total; nb0 += 64 * NB_REG) {
-                uint4 nb[NB_REG];
+            const int nch = (int)(((R.total - nb0 < (uint32_t)(64 * NB_REG) ? R.total - nb0 : (uint32_t)(64 * NB_REG)) + 63) / 64);
+            unsigned long long todo = alive;
+            while (todo) {
+                const int k = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint4 ce = c_rec[wv][k];
+                bool h = false;
 #pragma unroll
-                for (int k = 0; k < NB_REG; k++) {
-                    const uint32_t fi = nb0 + k * 64 + lane;
-                    nb[k] = fi < R.total ? P.rec[run_pos(R, fi)] : make_uint4(0, 0, 0, ST_SUPPRESSED);
+                for (int j = 0; j < NB_REG; j++) {
+                    if (j >= nch) break; // uniform
+                    // a point accepted earlier in THIS phase (NEW) was undecided when the round began
+                    h = h || ((nb[j].w == ST_UNDECIDED || nb[j].w == ST_NEW) && nq[j] != pb + (uint32_t)k &&
+                              within(nb[j].x, ce.x, r2) && better((int)nb[j].y, nb[j].z, (int)ce.y, ce.z));
                 }
-#pragma unroll
-                for (int k = 0; k < NB_REG; k++) {
-                    unsigned long long acc = __ballot(nb[k].w == ST_NEW || nb[k].w == ST_ACCEPTED);
-                    while (acc) {
-                        const int b = __builtin_ctzll(acc);
-                        acc &= acc - 1;
-                        const uint32_t axy = (uint32_t)__shfl((int)nb[k].x, b);
-                        sup = sup || within(me.x, axy, r2);
-                    }
-                }
+                if (__any(h)) alive &= ~(1ull << k);
             }
-            if (und && sup) { *rec_state(P.rec, p) = ST_SUPPRESSED; me.w = ST_SUPPRESSED; }
-            und_left += (uint32_t)__popcll(__ballot(have && me.w == ST_UNDECIDED));
+        }
+        if (alive) { // nobody better within r: accept, and queue for this round's suppression pass
+            const bool mine = (alive >> lane) & 1ull;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&P.counters[round & 1], (uint32_t)__popcll(alive));
+            base = (uint32_t)__shfl((int)base, 0);
+            if (mine) {
+                *rec_state(P.rec, p) = ST_NEW;
+                P.listA[base + (uint32_t)__popcll(alive & ((1ull << lane) - 1ull))] = p;
+            }
         }
     }
-    if (PHASE == 1 && lane == 0) P.cell_und[c] = und_left;
+    if (und_seen == 0 && lane == 0) P.cell_und[c] = 0; // everything here was decided by last round's suppression pass
+}
+
+// Phase B, one wavefront per NEWLY accepted point (a few thousand per frame over all rounds): retire
+// it to ACCEPTED, emit its sort key, and suppress every undecided point within r (lanes = neighbours).
+__global__ __launch_bounds__(256) void k_nms_push(NmsLayout L, int radius, int round, unsigned char *ws_all,
+                                                  size_t ws_stride)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
+    const uint32_t nnew = P.counters[round & 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.counters[(round + 1) & 1] = 0; // next round's list starts empty
+    const long long r2 = (long long)radius * (long long)radius;
+    for (uint32_t a = blockIdx.x * 4 + wv; a < nnew; a += gridDim.x * 4) {
+        const uint32_t p = P.listA[a];
+        const uint4 me = P.rec[p];
+        const int cx = (int)(me.x & 0xFFFFu) / L.cs, cy = (int)(me.x >> 16) / L.cs;
+        const Runs R = cell_runs(P, L, cx, cy);
+        for (uint32_t nb0 = 0; nb0 < R.total; nb0 += 64 * NB_REG) {
+            uint4 nb[NB_REG];
+            uint32_t nq[NB_REG];
+#pragma unroll
+            for (int k = 0; k < NB_REG; k++) {
+                const uint32_t fi = nb0 + k * 64 + lane;
+                nq[k] = fi < R.total ? run_pos(R, fi) : 0xFFFFFFFFu;
+                nb[k] = fi < R.total ? P.rec[nq[k]] : make_uint4(0, 0, 0, ST_SUPPRESSED);
+            }
+#pragma unroll
+            for (int k = 0; k < NB_REG; k++)
+                if (nb[k].w == ST_UNDECIDED && within(nb[k].x, me.x, r2)) *rec_state(P.rec, nq[k]) = ST_SUPPRESSED;
+        }
+        if (lane == 0) {
+            *rec_state(P.rec, p) = ST_ACCEPTED;
+            P.sortkeys[atomicAdd(&P.counters[2], 1u)] = sort_key((int)me.y, me.z);
+        }
+    }
 }
 
 __device__ void bitonic_sort_u64(unsigned long long *keys, uint32_t n2p)
@@ -402,7 +430,11 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
             __syncthreads();
             for (int a = tid; a < n_act; a += NT) {
                 const uint32_t p = cur[a];
-                if (P.rec[p].w == ST_NEW) *rec_state(P.rec, p) = ST_ACCEPTED;
+                const uint4 me = P.rec[p];
+                if (me.w == ST_NEW) {
+                    *rec_state(P.rec, p) = ST_ACCEPTED;
+                    P.sortkeys[atomicAdd(&P.counters[2], 1u)] = sort_key((int)me.y, me.z);
+                }
             }
             n_act = (int)sh_cnt;
             uint32_t *t = cur; cur = nxt; nxt = t;
@@ -410,22 +442,18 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
         }
     }
 
-    // ---- gather the accepted points: key = (score descending, input index ascending) ----
-    const bool all_accepted = radius < 0; // distance > r is always true for r < 0
-    if (tid == 0) sh_cnt = 0;
+    // ---- the accepted points' keys (score descending, input index ascending) were appended as they were
+    //      accepted; only the degenerate r < 0 case ("distance > r" is always true) gathers everything here
     __syncthreads();
-    for (int p = tid; p < n; p += NT) {
-        int sc;
-        uint32_t id;
-        bool acc;
-        if (all_accepted) { acc = true; sc = raw_score[p]; id = (uint32_t)p; }
-        else { const uint4 me = P.rec[p]; acc = me.w == ST_ACCEPTED; sc = (int)me.y; id = me.z; }
-        if (acc) {
-            const uint32_t inv = ~((uint32_t)sc ^ 0x80000000u); // larger score -> smaller key
-            P.sortkeys[atomicAdd(&sh_cnt, 1u)] = ((unsigned long long)inv << 32) | id;
-        }
+    if (radius < 0) {
+        if (tid == 0) sh_cnt = 0;
+        __syncthreads();
+        for (int p = tid; p < n; p += NT) P.sortkeys[atomicAdd(&sh_cnt, 1u)] = sort_key(raw_score[p], (uint32_t)p);
+        __syncthreads();
+    } else {
+        if (tid == 0) sh_cnt = P.counters[2];
+        __syncthreads();
     }
-    __syncthreads();
     const uint32_t nacc = sh_cnt;
     const uint32_t n2p = [](uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }(nacc > 1 ? nacc : 1);
     if (n2p <= SORT_LDS_MAX) {
@@ -491,8 +519,8 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
         hipLaunchKernelGGL(k_nms_cellscan, dim3(F), dim3(NT), 0, s, L, ws, ws_stride);
         hipLaunchKernelGGL(k_nms_scatter, pgrid, dim3(256), 0, s, raw_xy, raw_score, n_raw, n_cap, L, ws, ws_stride);
         for (int r = 0; r < WIDE_ROUNDS; r++) {
-            hipLaunchKernelGGL(k_nms_phase<0>, cgrid, dim3(256), 0, s, L, radius, ws, ws_stride);
-            hipLaunchKernelGGL(k_nms_phase<1>, cgrid, dim3(256), 0, s, L, radius, ws, ws_stride);
+            hipLaunchKernelGGL(k_nms_phase_a, cgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
+            hipLaunchKernelGGL(k_nms_push, dim3(r == 0 ? 256 : 64, F), dim3(256), 0, s, L, radius, r, ws, ws_stride);
         }
     }
     static bool attr_set = false;
