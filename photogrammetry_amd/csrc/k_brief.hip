@@ -87,13 +87,31 @@ __global__ __launch_bounds__(256) void k_brief_kept(const float *__restrict__ gr
                                                     const int32_t *__restrict__ n_kept, int kp_cap,
                                                     const int4 *__restrict__ pairs, int P, int words,
                                                     pgx_keypoint *__restrict__ kp_out, uint32_t *__restrict__ desc_out,
-                                                    int32_t *__restrict__ counts_out)
+                                                    int32_t *__restrict__ counts_out, int nframes)
 {
     __shared__ uint32_t wbuf[4][MAX_WORDS + 2];
-    const int f = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + wv;
+    // XCD-aware block -> (frame, keypoint block) map: consecutive workgroup ids are dealt round-robin to
+    // the 8 XCDs, so id % 8 picks the frame inside a group of 8 frames: all gathers of one frame then go
+    // through ONE XCD's L2 instead of eight (speed only; any mapping is correct).
+    const int nblk = (kp_cap + 3) / 4;
+    const int F8 = (nframes / 8) * 8;
+    int f, kb;
+    {
+        const int Lid = blockIdx.x;
+        if (Lid < nblk * F8) {
+            const int j = Lid >> 3;
+            f = (j / nblk) * 8 + (Lid & 7);
+            kb = j % nblk;
+        } else {
+            const int r = Lid - nblk * F8;
+            f = F8 + r / nblk;
+            kb = r % nblk;
+        }
+    }
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = kb * 4 + wv;
     const int nk = n_kept[f];
-    if (blockIdx.x == 0 && threadIdx.x == 0) counts_out[f] = nk;
+    if (kb == 0 && threadIdx.x == 0) counts_out[f] = nk;
     if (k >= nk) return; // wave-uniform
     const uint32_t ri = order[(size_t)f * kp_cap + k];
     const uint32_t xy = raw_xy[(size_t)f * raw_cap + ri];
@@ -131,9 +149,9 @@ void pgx_launch_brief(hipStream_t s, const float *gray, int F, int W, int H, con
 {
     if (F <= 0 || kp_cap <= 0) return;
     const int words = (P + 31) / 32;
-    hipLaunchKernelGGL(k_brief_kept, dim3((kp_cap + 3) / 4, F), dim3(256), 0, s, gray, W, H, raw_xy, raw_score,
+    hipLaunchKernelGGL(k_brief_kept, dim3(((kp_cap + 3) / 4) * F), dim3(256), 0, s, gray, W, H, raw_xy, raw_score,
                        raw_cap, order, n_kept, kp_cap, reinterpret_cast<const int4 *>(pairs), P, words, kp_out,
-                       desc_out, counts_out);
+                       desc_out, counts_out, F);
 }
 
 void pgx_launch_brief_list(hipStream_t s, const float *gray, int W, int H, const pgx_keypoint *kps, int n,

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_ham_valu(uint32_t *ws, const uint32_t *
     PairWs p = pair_ws(ws, m, S);
     const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2], parity = p.cnt[CNT_PARITY];
     if (n1 <= 0 || n2 <= 0) return;
-    if (n1 <= PGX_TAIL_MAX && n2 <= PGX_TAIL_MAX) return; // the per-pair tail kernel takes it from here
+    if (n1 <= PGX_TAIL_FILL_MAX && n2 <= PGX_TAIL_FILL_MAX) return; // small enough: the per-pair tail kernel takes it from here
     const uint32_t *dA = desc + (size_t)pairlist[2 * m] * S * words;
     const uint32_t *dB = desc + (size_t)pairlist[2 * m + 1] * S * words;
     const int nR = side ? n2 : n1, nC = side ? n1 : n2;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(SEL_NT) void k_match_select(uint32_t *ws, int S, un
     __shared__ uint32_t wsum[SEL_NT / 64];
     PairWs p = pair_ws(ws, blockIdx.x, S);
     if (p.cnt[CNT_N1] <= 0 || p.cnt[CNT_N2] <= 0) return;
-    if (p.cnt[CNT_N1] <= PGX_TAIL_MAX && p.cnt[CNT_N2] <= PGX_TAIL_MAX) return; // round was skipped
+    if (p.cnt[CNT_N1] <= PGX_TAIL_FILL_MAX && p.cnt[CNT_N2] <= PGX_TAIL_FILL_MAX) return; // round was skipped
     const int parity = p.cnt[CNT_PARITY];
     if (threadIdx.x == 0) atomicAdd(evals, (unsigned long long)p.cnt[CNT_N1] * (unsigned long long)p.cnt[CNT_N2]);
     select_compact_wg(p, parity, wsum);
@@ -303,7 +303,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 __host__ __device__ inline size_t tail_lds_words(int W)
 {
     // rl, cl, rbest, cbest, rdl, cdl (6 x TAIL_MAX) + alive flags (2 x TAIL_MAX bytes) + 8 counters + descriptors
-    return (size_t)6 * TAIL_MAX + (size_t)2 * TAIL_MAX / 4 + 8 + (size_t)2 * TAIL_MAX * W;
+    return (size_t)6 * TAIL_MAX + (size_t)2 * TAIL_MAX / 4 + 8 + (size_t)2 * PGX_TAIL_FILL_MAX * W;
 }
 
 // Wide fill of the tail's cached distance matrices: once an image pair's residual fits the tail
@@ -372,7 +372,8 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
     uint32_t *rdl = cbest + TAIL_MAX, *cdl = rdl + TAIL_MAX;
     uint8_t *ralive = reinterpret_cast<uint8_t *>(cdl + TAIL_MAX), *calive = ralive + TAIL_MAX;
     uint32_t *ctr = reinterpret_cast<uint32_t *>(calive + TAIL_MAX); // [0] dirty rows [1] dirty cols [2] accepted [3] alive rows [4] alive cols
-    uint32_t *rdesc = ctr + 8, *cdesc = rdesc + (size_t)TAIL_MAX * W;
+    uint32_t *rdesc = ctr + 8, *cdesc = rdesc + (size_t)PGX_TAIL_FILL_MAX * W; // only used when this kernel fills D itself
+    const bool prefilled = p.cnt[CNT_FILLED] != 0;
     const uint32_t *rows = (parity ? p.rows1 : p.rows0), *cols = (parity ? p.cols1 : p.cols0);
 
     __syncthreads();
@@ -380,9 +381,10 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
     __syncthreads();
     for (int i = tid; i < R; i += nth) { rl[i] = rows[i]; rdl[i] = (uint32_t)i; ralive[i] = 1; rbest[i] = PGX_KEY_NONE; }
     for (int j = tid; j < C; j += nth) { cl[j] = cols[j]; cdl[j] = (uint32_t)j; calive[j] = 1; cbest[j] = PGX_KEY_NONE; }
-    // word-major images (desc[w][k]) so that lanes reading neighbouring descriptors hit neighbouring banks
-    for (int t = tid; t < R * W; t += nth) rdesc[(size_t)(t % W) * TAIL_MAX + t / W] = dA[(size_t)rows[t / W] * W + (t % W)];
-    for (int t = tid; t < C * W; t += nth) cdesc[(size_t)(t % W) * TAIL_MAX + t / W] = dB[(size_t)cols[t / W] * W + (t % W)];
+    if (!prefilled) { // word-major images (desc[w][k]) so that lanes reading neighbouring descriptors hit neighbouring banks
+        for (int t = tid; t < R * W; t += nth) rdesc[(size_t)(t % W) * PGX_TAIL_FILL_MAX + t / W] = dA[(size_t)rows[t / W] * W + (t % W)];
+        for (int t = tid; t < C * W; t += nth) cdesc[(size_t)(t % W) * PGX_TAIL_FILL_MAX + t / W] = dB[(size_t)cols[t / W] * W + (t % W)];
+    }
     if (tid == 0) { ctr[0] = (uint32_t)R; ctr[1] = (uint32_t)C; ctr[2] = 0; ctr[3] = 0; ctr[4] = 0; }
     __syncthreads();
 
@@ -397,15 +399,15 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
                 if (WORDS > 0) {
 #pragma unroll
                     for (int w = 0; w < WORDS; w++) {
-                        const uint32_t a = xdesc[(size_t)w * TAIL_MAX + i];
-                        const uint2 b = *reinterpret_cast<const uint2 *>(ydesc + (size_t)w * TAIL_MAX + j2);
+                        const uint32_t a = xdesc[(size_t)w * PGX_TAIL_FILL_MAX + i];
+                        const uint2 b = *reinterpret_cast<const uint2 *>(ydesc + (size_t)w * PGX_TAIL_FILL_MAX + j2);
                         d0 += __popc(a ^ b.x);
                         d1 += __popc(a ^ b.y);
                     }
                 } else {
                     for (int w = 0; w < W; w++) {
-                        const uint32_t a = xdesc[(size_t)w * TAIL_MAX + i];
-                        const uint2 b = *reinterpret_cast<const uint2 *>(ydesc + (size_t)w * TAIL_MAX + j2);
+                        const uint32_t a = xdesc[(size_t)w * PGX_TAIL_FILL_MAX + i];
+                        const uint2 b = *reinterpret_cast<const uint2 *>(ydesc + (size_t)w * PGX_TAIL_FILL_MAX + j2);
                         d0 += __popc(a ^ b.x);
                         d1 += __popc(a ^ b.y);
                     }
@@ -424,7 +426,7 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
             if (lane == 0) bestout[i] = best;
         }
     };
-    if (p.cnt[CNT_FILLED]) { // done by k_tail_fill on the whole chip; pick up the first bests
+    if (prefilled) { // done by k_tail_fill on the whole chip; pick up the first bests
         for (int i = tid; i < R; i += nth) rbest[i] = p.rowkey[i];
         for (int j = tid; j < C; j += nth) cbest[j] = p.colkey[j];
     } else {
@@ -441,45 +443,45 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
                           int nlist, uint32_t *bestout) {
         for (int k0 = wv * 4; k0 < nlist; k0 += nw * 4) {
             int idx[4];
-            uint4 v[4][2];
+            uint32_t best[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                idx[u] = (k0 + u < nlist) ? (int)list[k0 + u] : -1;
+            for (int u = 0; u < 4; u++) { idx[u] = (k0 + u < nlist) ? (int)list[k0 + u] : -1; best[u] = PGX_KEY_NONE; }
+            for (int q0 = 0; q0 < n; q0 += 1024) { // two 512-entry chunks (8 loads) in flight per pass
+                uint4 v[4][2];
+                uint2 al[2];
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
-                    const int j8 = lane * 8 + q * 512;
-                    v[u][q] = (idx[u] >= 0 && j8 < n) ? *reinterpret_cast<const uint4 *>(mat + (size_t)idx[u] * stride + j8)
-                                                      : make_uint4(~0u, ~0u, ~0u, ~0u);
+                    const int j8 = q0 + lane * 8 + q * 512;
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        v[u][q] = (idx[u] >= 0 && j8 < n) ? *reinterpret_cast<const uint4 *>(mat + (size_t)idx[u] * stride + j8)
+                                                          : make_uint4(~0u, ~0u, ~0u, ~0u);
+                    al[q] = (j8 < n) ? *reinterpret_cast<const uint2 *>(alive + j8) : make_uint2(0, 0);
                 }
-            }
-            uint2 al[2];
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int j8 = lane * 8 + q * 512;
-                al[q] = (j8 < n) ? *reinterpret_cast<const uint2 *>(alive + j8) : make_uint2(0, 0);
-            }
+                for (int u = 0; u < 4; u++) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                uint32_t best = PGX_KEY_NONE;
+                    for (int q = 0; q < 2; q++) {
+                        const int j8 = q0 + lane * 8 + q * 512;
+                        const uint32_t dw[4] = {v[u][q].x, v[u][q].y, v[u][q].z, v[u][q].w};
 #pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const int j8 = lane * 8 + q * 512;
-                    const uint32_t dw[4] = {v[u][q].x, v[u][q].y, v[u][q].z, v[u][q].w};
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const uint32_t d = (dw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-                        const uint32_t a = ((k < 4 ? al[q].x : al[q].y) >> (8 * (k & 3))) & 0xFFu;
-                        const uint32_t key = a ? ((d << PGX_IDX_BITS) | (uint32_t)(j8 + k)) : PGX_KEY_NONE;
-                        best = key < best ? key : best;
+                        for (int k = 0; k < 8; k++) {
+                            const uint32_t d = (dw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                            const uint32_t a = ((k < 4 ? al[q].x : al[q].y) >> (8 * (k & 3))) & 0xFFu;
+                            const uint32_t key = a ? ((d << PGX_IDX_BITS) | (uint32_t)(j8 + k)) : PGX_KEY_NONE;
+                            best[u] = key < best[u] ? key : best[u];
+                        }
                     }
                 }
-                best = wave_min_u32(best);
-                if (lane == 0 && idx[u] >= 0) bestout[idx[u]] = best;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t bst = wave_min_u32(best[u]);
+                if (lane == 0 && idx[u] >= 0) bestout[idx[u]] = bst;
             }
         }
     };
 
-    if (tid == 0) { atomicAdd(&dbg[0], 1); atomicAdd(&dbg[1], R); atomicAdd(&dbg[2], C); }
     while (true) {
         const int nrd = (int)ctr[0], ncd = (int)ctr[1];
         if (tid == 0) { atomicAdd(&dbg[3], 1); atomicAdd(&dbg[4], nrd); atomicAdd(&dbg[5], ncd); }
@@ -542,7 +544,8 @@ __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uin
     while (true) {
         const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2];
         if (n1 <= 0 || n2 <= 0) break; // uniform: cnt is only written behind barriers
-        if (tail_in_lds && n1 <= TAIL_MAX && n2 <= TAIL_MAX) {
+        const int lim = p.cnt[CNT_FILLED] ? TAIL_MAX : PGX_TAIL_FILL_MAX; // without the wide fill the descriptors must fit LDS
+        if (tail_in_lds && n1 <= lim && n2 <= lim) {
             tail_rounds_lds<WORDS>(p, parity, dA, dB, words, lds, status + 24);
             break;
         }

@@ -113,8 +113,8 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     if (M <= 0) return PGX_OK;
     if (stride <= 0 || stride > (1 << PGX_IDX_BITS)) return fail(c, PGX_E_BADARG, "stride must be in [1, 2^20]");
     if (words <= 0 || words > 127) return fail(c, PGX_E_BADARG, "words must be in [1, 127] (P <= 4064)");
-    // image pairs go through in chunks so the per-pair workspace (incl. the tail's 4 MiB distance cache) stays bounded
-    const int CHUNK = 256;
+    // image pairs go through in chunks so the per-pair workspace (incl. the tail's 16 MiB distance cache) stays bounded
+    const int CHUNK = 128;
     const int mc = M < CHUNK ? M : CHUNK;
     HIPCHK(c, c->ws_match.ensure(pgx_match_ws_bytes(mc, stride)));
     MatchPlan plan;
@@ -123,7 +123,7 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     // all-CU rounds until the residual fits the LDS tail (random data halves per round; each launch
     // skips image pairs that already fit, so extra rounds only cost their launch)
     plan.rounds_mfma = 0;
-    for (int n = plan.max_n; n > PGX_TAIL_MAX && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
+    for (int n = plan.max_n; n > PGX_TAIL_FILL_MAX && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
     if (plan.rounds_mfma > 0 && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS) plan.rounds_mfma++;
     HIPCHK(c, hipMemsetAsync(c->d_status + 4, 0, PGX_MAX_WIDE_ROUNDS * 8, c->stream));
     for (int m0 = 0; m0 < M; m0 += CHUNK) {

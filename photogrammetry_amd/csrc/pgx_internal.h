@@ -25,7 +25,9 @@
 // d_status layout (ints): [0] sticky error bits, [4..4+2*PGX_MAX_WIDE_ROUNDS) u64 evaluation counters per wide round
 #define PGX_MAX_WIDE_ROUNDS 8
 // residual size (rows and columns) from which one workgroup finishes an image pair out of LDS
-#define PGX_TAIL_MAX 1024
+#define PGX_TAIL_MAX 2048
+// ... and the limit when the tail workgroup has to fill its distance cache itself (descriptors staged in LDS)
+#define PGX_TAIL_FILL_MAX 1024
 
 struct DevBuf {
     void *p = nullptr;
