@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dewarp", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="steps kept in flight (one pgx context + HIP stream each)")
     args = ap.parse_args()
 
     import torch
@@ -125,32 +126,42 @@ def main():
     frames_h = make_inputs(B, rank)
     pairs = pg.make_brief_pairs(0, 50, P)
     dmap = None if args.no_dewarp else pg.build_dewarp_map(W, H, [3e-4, 1e-7, 0, 0, 0])
-    eng = pg.Engine(local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.set_brief_pairs(pairs)
-    eng.set_detect_params(THRESH, RADIUS)
-    eng.set_capacity(1 << 18, 8192)
-    eng.set_dewarp_map(dmap)
+    NS = max(1, args.streams)
     CAP = 8192
     d_frames = torch.from_numpy(frames_h).to(dev)
-    d_kp = torch.zeros((F, CAP, 4), dtype=torch.int32, device=dev)
-    d_desc = torch.zeros((F, CAP, WORDS), dtype=torch.int32, device=dev)
-    d_counts = torch.zeros(F, dtype=torch.int32, device=dev)
-    d_nraw = torch.zeros(F, dtype=torch.int32, device=dev)
     pairlist = torch.tensor([[2 * p, 2 * p + 1] for p in range(B)], dtype=torch.int32, device=dev)
-    d_out = torch.zeros((B, CAP, 3), dtype=torch.int32, device=dev)
-    log("[rank %d] setup %.1fs, %d frames resident (%.0f MB)" % (rank, time.time() - t_setup, F, d_frames.numel() * 2 / 1e6))
+    engs, bufs = [], []
+    for _ in range(NS):
+        e = pg.Engine(local_rank)          # own non-blocking HIP stream per context
+        e.set_brief_pairs(pairs)
+        e.set_detect_params(THRESH, RADIUS)
+        e.set_capacity(1 << 18, 8192)
+        e.set_dewarp_map(dmap)
+        engs.append(e)
+        bufs.append(dict(kp=torch.zeros((F, CAP, 4), dtype=torch.int32, device=dev),
+                         desc=torch.zeros((F, CAP, WORDS), dtype=torch.int32, device=dev),
+                         counts=torch.zeros(F, dtype=torch.int32, device=dev),
+                         nraw=torch.zeros(F, dtype=torch.int32, device=dev),
+                         out=torch.zeros((B, CAP, 3), dtype=torch.int32, device=dev)))
+    eng = engs[0]
+    d_counts, d_nraw, d_out = bufs[0]["counts"], bufs[0]["nraw"], bufs[0]["out"]
+    torch.cuda.synchronize()
+    log("[rank %d] setup %.1fs, %d frames resident (%.0f MB), %d stream(s)" % (rank, time.time() - t_setup, F, d_frames.numel() * 2 / 1e6, NS))
+    step_no = [0]
 
     def step():
-        eng.detect_batch_dev(d_frames, F, W, H, d_kp, d_desc, d_counts, d_nraw, CAP)
-        eng.match_batch_dev(d_desc, d_counts, CAP, WORDS, pairlist, B, d_out, max_count=NKP)
+        k = step_no[0] % NS
+        step_no[0] += 1
+        e, b = engs[k], bufs[k]
+        e.detect_batch_dev(d_frames, F, W, H, b["kp"], b["desc"], b["counts"], b["nraw"], CAP)
+        e.match_batch_dev(b["desc"], b["counts"], CAP, WORDS, pairlist, B, b["out"], max_count=NKP)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, NS)):
         step()
     torch.cuda.synchronize()
     # NMS survivors above the output capacity only flag a truncation here; anything else is fatal
@@ -164,15 +175,17 @@ def main():
     pairs_per_step = int(sum(int(n_used[2 * p]) * int(n_used[2 * p + 1]) for p in range(B)))
     log("[rank %d] survivors per frame %s, raw %s" % (rank, counts.tolist(), nraw.tolist()))
 
-    eng.profile_reset()
-    eng.profile_enable(True)
+    for e in engs:
+        e.profile_reset()
+        e.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    eng.profile_enable(False)
+    for e in engs:
+        e.profile_enable(False)
 
     # one exchange step: every rank's match lists -> all ranks (input of the track graph)
     if world > 1:
@@ -191,7 +204,10 @@ def main():
     if rank == 0:
         kern = {}
         for name in ("dewarp_gray", "fast", "nms", "brief", "match_init", "ham_argmin", "match_select", "tail_fill", "match_finish"):
-            n, ms = eng.profile_get(name)
+            n, ms = 0, 0.0
+            for e in engs:
+                n_e, ms_e = e.profile_get(name)
+                n, ms = n + n_e, ms + ms_e
             if n:
                 kern[name] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / args.steps}
         rounds_wide, evals, evals0 = eng.match_stats()
@@ -254,7 +270,7 @@ def main():
                                    "dewarp(%s)+gray+FAST(T=0.1)+NMS(r=%d)+BRIEF-256+greedy Hamming match, %d keypoints "
                                    "per frame (truncated to the first %d in NMS order)"
                                    % (B, B, "off" if dmap is None else "shipped coeffs", RADIUS, NKP, NKP),
-                       "pairs_per_step_per_gpu": B, "keypoints": [int(x) for x in n_used.tolist()],
+                       "pairs_per_step_per_gpu": B, "streams": NS, "keypoints": [int(x) for x in n_used.tolist()],
                        "raw_hits": [int(x) for x in nraw.tolist()], "parallelism": "pair-sharded x%d" % world},
             "roofline": roof,
             "rooflines": rooflines,
@@ -277,7 +293,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    for e in engs:
+        e.close()
 
 
 if __name__ == "__main__":

@@ -39,7 +39,8 @@ struct NmsLayout {
 __host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_cap)
 {
     NmsLayout L;
-    int cs = radius > 16 ? radius : 16;
+    // 16/32/64 keep cells aligned with the 64-pixel FAST row segments (plane-based binning); larger radii use r
+    int cs = radius <= 16 ? 16 : (radius <= 32 ? 32 : (radius <= 64 ? 64 : radius));
     L.cs = cs;
     L.gw = (W + cs - 1) / cs; if (L.gw < 1) L.gw = 1;
     L.gh = (H + cs - 1) / cs; if (L.gh < 1) L.gh = 1;
@@ -182,6 +183,54 @@ __global__ __launch_bounds__(256) void k_nms_scatter(const uint32_t *__restrict_
     const int cx = (int)(xy & 0xFFFFu) / L.cs, cy = (int)(xy >> 16) / L.cs;
     const uint32_t pos = atomicAdd(&P.cell_fill[cy * L.gw + cx], 1u);
     P.rec[pos] = make_uint4(xy, (uint32_t)raw_score_all[(size_t)f * n_cap + i], (uint32_t)i, ST_UNDECIDED);
+}
+
+// ---- atomic-free binning straight from the FAST ballot planes (fused detect path, cs in {16,32,64}) ----
+// seg[F][H][ntx][4] = three score-bit planes + count per 64-pixel row segment; segoff = raster-order offsets.
+// One thread per cell: MODE 0 counts the hits of its cs x cs pixels into cell_fill, MODE 1 (after the
+// cell scan) writes their records at cell_start[c]... in raster order.  The input index of a hit is its
+// raster rank = segoff + popcount(lower bits), exactly what k_fast_compact wrote into the raw list.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_nms_bin_planes(const unsigned long long *__restrict__ seg_all,
+                                                        const uint32_t *__restrict__ segoff_all, int W, int H, int ntx,
+                                                        int n_cap, NmsLayout L, unsigned char *ws_all, size_t ws_stride)
+{
+    const int f = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= L.ncell) return;
+    NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
+    const int cy = c / L.gw, cx = c - cy * L.gw;
+    const int x0 = cx * L.cs, tx = x0 >> 6, bo = x0 & 63;
+    const unsigned long long cmask = (L.cs >= 64 ? ~0ull : ((1ull << L.cs) - 1ull)) << bo;
+    const int y0 = cy * L.cs, y1 = (y0 + L.cs < H) ? y0 + L.cs : H;
+    const size_t nseg = (size_t)H * ntx;
+    const unsigned long long *seg = seg_all + (size_t)f * nseg * 4;
+    const uint32_t *segoff = segoff_all + (size_t)f * nseg;
+    uint32_t count = 0;
+    uint32_t pos = MODE ? P.cell_start[c] : 0u;
+    for (int y = y0; y < y1; y++) {
+        const size_t si = (size_t)y * ntx + tx;
+        const ulonglong2 p01 = *reinterpret_cast<const ulonglong2 *>(seg + si * 4);
+        const unsigned long long b2 = seg[si * 4 + 2];
+        const unsigned long long any = p01.x | p01.y | b2;
+        unsigned long long m = any & cmask;
+        if (!m) continue;
+        uint32_t idx = segoff[si] + (uint32_t)__popcll(any & ((1ull << bo) - 1ull)); // raster rank of the first hit here
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            if (idx < (uint32_t)n_cap) { // hits past the raw capacity are dropped everywhere (PGX_E_CAPACITY is raised)
+                if (MODE) {
+                    const int code = (int)((p01.x >> l) & 1ull) | ((int)((p01.y >> l) & 1ull) << 1) | ((int)((b2 >> l) & 1ull) << 2);
+                    P.rec[pos++] = make_uint4(((uint32_t)y << 16) | (uint32_t)(tx * 64 + l), (uint32_t)(code + 11), idx, ST_UNDECIDED);
+                } else {
+                    count++;
+                }
+            }
+            idx++;
+        }
+    }
+    if (!MODE) P.cell_fill[c] = count;
 }
 
 // The 3x3-cell neighbourhood of cell (cx, cy) as three runs of records, one flat index space.
@@ -505,7 +554,7 @@ size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap) { return nms_layout
 
 void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw, int F,
                     int n_cap, int W, int H, int radius, void *wsv, size_t ws_stride, uint32_t *order,
-                    int32_t *n_kept, int kp_cap, int *status)
+                    int32_t *n_kept, int kp_cap, int *status, const unsigned long long *seg, const uint32_t *segoff)
 {
     if (F <= 0) return;
     unsigned char *ws = reinterpret_cast<unsigned char *>(wsv);
@@ -514,10 +563,15 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
     const dim3 pgrid((n_cap + 255) / 256, F);
     const dim3 cgrid((L.ncell + 3) / 4, F);
     if (rounds) {
+        const bool planes = seg && segoff && (L.cs == 16 || L.cs == 32 || L.cs == 64);
+        const dim3 bgrid((L.ncell + 255) / 256, F);
+        const int ntx = (W + 63) / 64;
         hipLaunchKernelGGL(k_nms_zero, dim3((L.ncell + 256) / 256, F), dim3(256), 0, s, L, ws, ws_stride);
-        hipLaunchKernelGGL(k_nms_count, pgrid, dim3(256), 0, s, raw_xy, n_raw, n_cap, L, ws, ws_stride);
+        if (planes) hipLaunchKernelGGL(k_nms_bin_planes<0>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
+        else hipLaunchKernelGGL(k_nms_count, pgrid, dim3(256), 0, s, raw_xy, n_raw, n_cap, L, ws, ws_stride);
         hipLaunchKernelGGL(k_nms_cellscan, dim3(F), dim3(NT), 0, s, L, ws, ws_stride);
-        hipLaunchKernelGGL(k_nms_scatter, pgrid, dim3(256), 0, s, raw_xy, raw_score, n_raw, n_cap, L, ws, ws_stride);
+        if (planes) hipLaunchKernelGGL(k_nms_bin_planes<1>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
+        else hipLaunchKernelGGL(k_nms_scatter, pgrid, dim3(256), 0, s, raw_xy, raw_score, n_raw, n_cap, L, ws, ws_stride);
         for (int r = 0; r < WIDE_ROUNDS; r++) {
             hipLaunchKernelGGL(k_nms_phase_a, cgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
             hipLaunchKernelGGL(k_nms_push, dim3(r == 0 ? 256 : 64, F), dim3(256), 0, s, L, radius, r, ws, ws_stride);

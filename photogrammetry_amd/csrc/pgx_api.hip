@@ -95,7 +95,7 @@ int enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_
         ProfScope ps(c, "nms");
         pgx_launch_nms(c->stream, c->ws_rawxy.as<uint32_t>(), c->ws_rawscore.as<int32_t>(), d_nraw, F, raw_cap, W, H,
                        c->radius, c->ws_nms.p, nms_stride, c->ws_order.as<uint32_t>(), c->ws_nkept.as<int32_t>(),
-                       cap, c->d_status);
+                       cap, c->d_status, c->ws_seg.as<unsigned long long>(), c->ws_segoff.as<uint32_t>());
     }
     {
         ProfScope ps(c, "brief");

@@ -91,6 +91,26 @@ struct pgx_ctx {
     long long last_evals = 0;
 };
 
+// XCD-aware block -> (frame, block-in-frame) map for batched kernels whose blocks of one frame share data.
+// Workgroup ids are dealt round-robin to the 8 XCDs (observed, not contractual), so id % 8 selects the frame
+// inside a group of 8 frames and one frame's working set lives in ONE XCD's 4 MiB L2.  Speed only: any
+// mapping is correct.  Launch with a 1-D grid of nblk * F blocks.
+#ifdef __HIPCC__
+__device__ __forceinline__ void pgx_xcd_map(int lin, int nblk, int F, int &f, int &b)
+{
+    const int F8 = (F >> 3) << 3;
+    if (lin < nblk * F8) {
+        const int j = lin >> 3;
+        f = (j / nblk) * 8 + (lin & 7);
+        b = j % nblk;
+    } else {
+        const int r = lin - nblk * F8;
+        f = F8 + r / nblk;
+        b = r % nblk;
+    }
+}
+#endif
+
 // RAII event bracket used by the launchers' callers
 struct ProfScope {
     pgx_ctx *c;
@@ -130,7 +150,9 @@ void pgx_launch_fast(hipStream_t s, const float *gray, int F, int W, int H, floa
 size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap);  // per frame
 void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw,
                     int F, int n_cap, int W, int H, int radius, void *ws, size_t ws_stride,
-                    uint32_t *order /*[F][kp_cap]*/, int32_t *n_kept /*[F]*/, int kp_cap, int *status);
+                    uint32_t *order /*[F][kp_cap]*/, int32_t *n_kept /*[F]*/, int kp_cap, int *status,
+                    const unsigned long long *seg = nullptr /* FAST planes: enables atomic-free binning */,
+                    const uint32_t *segoff = nullptr);
 
 // k_brief.hip
 void pgx_launch_brief(hipStream_t s, const float *gray, int F, int W, int H,
