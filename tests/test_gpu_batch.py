@@ -1,0 +1,159 @@
+"""GPU tests of the device-resident batched entry points (pgx_detect_batch_dev / pgx_match_batch_dev):
+several frames per launch (frame counts that are and are not multiples of 8, which exercises both branches
+of the XCD-aware block mapping), ragged keypoint counts, `max_count` truncation, more image pairs than one
+workspace chunk (128), and the profiling hooks.  Everything is compared with the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+from photogrammetry_amd import synth
+import photogrammetry_amd as pg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def engine():
+    """Own context: these tests change capacities, BRIEF pairs and the dewarp map."""
+    e = pg.Engine(0)
+    yield e
+    e.close()
+
+
+def _oracle_detect(frame, dmap, pairs, T, radius, cap):
+    src = cref.apply_distortion(frame, dmap) if dmap is not None else frame
+    g = cref.gray(src)
+    raw = cref.detect(g, T)
+    kept = raw[cref.nms(raw, radius)][:cap]
+    return kept, cref.brief(g, np.stack([kept["x"], kept["y"]], 1), pairs), len(raw)
+
+
+@pytest.mark.parametrize("F,radius,with_map", [(3, 9, True), (8, 16, False), (11, 20, True)])
+def test_detect_batch_matches_oracle(engine, F, radius, with_map):
+    W, H, CAP = 320, 240, 2048
+    T = np.float32(0.1)
+    frames = np.stack([synth.make_frame(W, H, seed=50 + i, n_shapes=40 + 37 * i) for i in range(F)])
+    frames[F - 1][...] = synth.make_frame(W, H, seed=1, n_shapes=0)   # a frame with no keypoints at all
+    pairs = pg.make_brief_pairs(3, 30, 256)
+    dmap = pg.build_dewarp_map(W, H, [3e-4, 1e-7, 0, 0, 0]) if with_map else None
+    engine.set_brief_pairs(pairs)
+    engine.set_detect_params(T, radius)
+    engine.set_capacity(1 << 16, CAP)
+    engine.set_dewarp_map(dmap)
+    d_frames = torch.from_numpy(frames).to(DEV)
+    d_kp = torch.zeros((F, CAP, 4), dtype=torch.int32, device=DEV)
+    d_desc = torch.zeros((F, CAP, 8), dtype=torch.int32, device=DEV)
+    d_counts = torch.full((F,), -1, dtype=torch.int32, device=DEV)
+    d_nraw = torch.full((F,), -1, dtype=torch.int32, device=DEV)
+    engine.detect_batch_dev(d_frames, F, W, H, d_kp, d_desc, d_counts, d_nraw, CAP)
+    engine.check_status()
+    kp = d_kp.cpu().numpy()
+    desc = d_desc.cpu().numpy().view(np.uint32)
+    counts, nraw = d_counts.cpu().numpy(), d_nraw.cpu().numpy()
+    assert counts[F - 1] == 0 and nraw[F - 1] == 0
+    for f in range(F):
+        kept, edesc, n_raw = _oracle_detect(frames[f], dmap, pairs, T, radius, CAP)
+        assert nraw[f] == n_raw and counts[f] == len(kept), f
+        n = len(kept)
+        assert (kp[f, :n, 0] == kept["x"]).all() and (kp[f, :n, 1] == kept["y"]).all()
+        assert (kp[f, :n, 2] == kept["fast_score"]).all()
+        assert kp[f, :n, 3].view(np.float32).tobytes() == kept["value"].tobytes()
+        assert (desc[f, :n] == edesc).all()
+    engine.set_dewarp_map(None)
+
+
+def _match_batch(engine, descs, counts, pairlist, stride, max_count=None):
+    F = len(descs)
+    d = np.zeros((F, stride, 8), dtype=np.uint32)
+    for f in range(F):
+        d[f, :len(descs[f])] = descs[f]
+    d_desc = torch.from_numpy(d.view(np.int32)).to(DEV)
+    d_counts = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    d_pl = torch.tensor(pairlist, dtype=torch.int32, device=DEV)
+    d_out = torch.full((len(pairlist), stride, 3), -7, dtype=torch.int32, device=DEV)
+    engine.match_batch_dev(d_desc, d_counts, stride, 8, d_pl, len(pairlist), d_out, max_count=max_count)
+    _match_batch.keepalive = (d_desc, d_counts, d_pl)   # the launch is asynchronous: inputs must outlive it
+    return d_out
+
+
+def test_match_batch_ragged_counts_and_order(engine):
+    rng = np.random.default_rng(5)
+    sizes = [1500, 40, 2300, 1024, 1025, 0, 700]
+    descs = [rng.integers(0, 2**32, (n, 8), dtype=np.uint32) for n in sizes]
+    descs[3] = descs[0][:1024].copy()                      # frame 3 is a prefix of frame 0: exact matches exist
+    pl = [(0, 2), (2, 0), (1, 4), (4, 1), (3, 0), (0, 3), (5, 6), (6, 6), (1, 1)]
+    d_out = _match_batch(engine, descs, sizes, pl, 2304)
+    engine.check_status()          # synchronises the engine's stream; results are not defined before it
+    out = d_out.cpu().numpy()
+    for m, (a, b) in enumerate(pl):
+        if sizes[a] == 0:
+            continue
+        exp = cref.match_sorted(descs[a], descs[b])
+        got = out[m][:sizes[a]]
+        assert (got[:, 0] == exp["k1"]).all() and (got[:, 1] == exp["k2"]).all() and (got[:, 2] == exp["dist"]).all(), (a, b)
+
+
+def test_match_batch_empty_second_set_raises(engine):
+    rng = np.random.default_rng(6)
+    descs = [rng.integers(0, 2**32, (30, 8), dtype=np.uint32), np.zeros((0, 8), np.uint32)]
+    out = _match_batch(engine, descs, [30, 0], [(0, 1), (0, 0)], 64)
+    with pytest.raises(pg.ArgumentOutOfRangeException):     # KeypointMatching.cs:61
+        engine.check_status()
+    o = out.cpu().numpy()
+    assert (o[0, :30, 2] == pg.api.PGX_DIST_NONE).all()     # the failed pair is all (0,0,int.MaxValue)
+    exp = cref.match(descs[0], descs[0])
+    assert (o[1, :30, 1] == exp["k2"]).all()                # the other pair of the batch is unaffected
+
+
+def test_match_batch_max_count_truncates(engine):
+    rng = np.random.default_rng(7)
+    descs = [rng.integers(0, 2**32, (900, 8), dtype=np.uint32), rng.integers(0, 2**32, (1300, 8), dtype=np.uint32)]
+    d_out = _match_batch(engine, descs, [900, 1300], [(0, 1), (1, 0)], 1536, max_count=512)
+    engine.check_status()
+    out = d_out.cpu().numpy()
+    for m, (a, b) in enumerate([(0, 1), (1, 0)]):
+        exp = cref.match_sorted(descs[a][:512], descs[b][:512])   # lists are cut to their first max_count entries
+        got = out[m][:512]
+        assert (got[:, 0] == exp["k1"]).all() and (got[:, 1] == exp["k2"]).all() and (got[:, 2] == exp["dist"]).all()
+
+
+def test_match_batch_more_pairs_than_one_chunk(engine):
+    """300 image pairs > the 128-pair workspace chunk; every pair checked against the oracle."""
+    rng = np.random.default_rng(8)
+    F = 25
+    sizes = [int(x) for x in rng.integers(50, 400, F)]
+    base = rng.integers(0, 2**32, (400, 8), dtype=np.uint32)
+    descs = []
+    for f in range(F):
+        d = base[rng.permutation(400)[:sizes[f]]].copy()
+        d[:, 7] ^= rng.integers(0, 4, sizes[f]).astype(np.uint32)   # near-duplicates across frames: tie-heavy
+        descs.append(d)
+    pl = [(a, b) for a in range(F) for b in range(a + 1, F)]
+    assert len(pl) == 300
+    d_out = _match_batch(engine, descs, sizes, pl, 400)
+    engine.check_status()
+    out = d_out.cpu().numpy()
+    for m, (a, b) in enumerate(pl):
+        exp = cref.match_sorted(descs[a], descs[b])
+        got = out[m][:sizes[a]]
+        assert (got[:, 0] == exp["k1"]).all() and (got[:, 1] == exp["k2"]).all() and (got[:, 2] == exp["dist"]).all(), (a, b)
+
+
+def test_profile_hooks_and_stats(engine):
+    rng = np.random.default_rng(9)
+    descs = [rng.integers(0, 2**32, (2000, 8), dtype=np.uint32) for _ in range(2)]
+    engine.profile_reset()
+    engine.profile_enable(True)
+    _match_batch(engine, descs, [2000, 2000], [(0, 1)], 2048)
+    engine.check_status()
+    engine.profile_enable(False)
+    n, ms = engine.profile_get("ham_argmin")
+    assert n >= 1 and ms > 0
+    n2, ms2 = engine.profile_get("match_finish")
+    assert n2 == 1 and ms2 > 0
+    rounds, evals, ev0 = engine.match_stats()
+    assert rounds >= 1 and ev0 == 2000 * 2000 and evals >= ev0
+    engine.profile_reset()
+    assert engine.profile_get("ham_argmin") == (0, 0.0)
