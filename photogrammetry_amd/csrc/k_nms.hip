@@ -33,18 +33,34 @@ constexpr uint32_t SORT_LDS_MAX = 16384; // u64 keys -> 128 KiB
 
 struct NmsLayout {
     int gw, gh, cs, ncell;
-    size_t off_cellstart, off_cellfill, off_cellund, off_counters, off_rec, off_listA, off_listB, off_accflag, off_sortkeys, total;
+    int R;     // neighbourhood reach in cells: every point within r of a cell's point lies in the (2R+1)^2 block
+    int champ; // 1: "champion" rounds (cells small enough that any two points of a cell are within r)
+    int cgw;   // width of the champion grid, padded by R empty cells on every side
+    size_t off_cellstart, off_cellfill, off_cellund, off_counters, off_rec, off_listA, off_listB, off_accflag, off_sortkeys,
+        off_champ, total;
 };
 
-__host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_cap)
+// champion rounds need: the FAST planes (cells aligned to the 64-pixel segments, scores 12..16, raster ranks),
+// a cell size cs in {8,16,32,64} with 2*(cs-1)^2 <= r^2, reach <= 3 cells, and ranks that fit 24 bits
+__host__ __device__ inline int nms_champ_cs(int radius, int n_cap, bool planes)
+{
+    if (!planes || radius < 10 || radius > 192 || n_cap > (1 << 24)) return 0;
+    return radius >= 90 ? 64 : (radius >= 44 ? 32 : (radius >= 22 ? 16 : 8));
+}
+
+__host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_cap, bool planes)
 {
     NmsLayout L;
-    // 16/32/64 keep cells aligned with the 64-pixel FAST row segments (plane-based binning); larger radii use r
-    int cs = radius <= 16 ? 16 : (radius <= 32 ? 32 : (radius <= 64 ? 64 : radius));
+    const int ccs = nms_champ_cs(radius, n_cap, planes);
+    // otherwise 16/32/64 keep cells aligned with the 64-pixel FAST row segments (plane-based binning); larger radii use r
+    int cs = ccs ? ccs : (radius <= 16 ? 16 : (radius <= 32 ? 32 : (radius <= 64 ? 64 : radius)));
     L.cs = cs;
+    L.champ = ccs ? 1 : 0;
+    L.R = ccs ? (radius + cs - 1) / cs : 1;
     L.gw = (W + cs - 1) / cs; if (L.gw < 1) L.gw = 1;
     L.gh = (H + cs - 1) / cs; if (L.gh < 1) L.gh = 1;
     L.ncell = L.gw * L.gh;
+    L.cgw = L.gw + 2 * L.R;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     L.off_cellstart = take((size_t)(L.ncell + 1) * 4);
@@ -56,6 +72,7 @@ __host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_
     L.off_listB = take((size_t)n_cap * 4);
     L.off_accflag = take((size_t)n_cap);
     L.off_sortkeys = take((size_t)n_cap * 8);
+    L.off_champ = take(L.champ ? (size_t)L.cgw * (L.gh + 2 * L.R) * 8 : 0);
     L.total = o;
     return L;
 }
@@ -67,6 +84,7 @@ struct NmsPtrs {
     uint4 *rec;
     uint8_t *accflag;
     unsigned long long *sortkeys;
+    uint2 *champ; // champion rounds: per cell {priority key of its best undecided point (0 = none), its xy}, padded grid
 };
 
 __device__ __forceinline__ NmsPtrs nms_ptrs(unsigned char *ws, const NmsLayout &L)
@@ -81,6 +99,7 @@ __device__ __forceinline__ NmsPtrs nms_ptrs(unsigned char *ws, const NmsLayout &
     p.listB = reinterpret_cast<uint32_t *>(ws + L.off_listB);
     p.accflag = reinterpret_cast<uint8_t *>(ws + L.off_accflag);
     p.sortkeys = reinterpret_cast<unsigned long long *>(ws + L.off_sortkeys);
+    p.champ = reinterpret_cast<uint2 *>(ws + L.off_champ);
     return p;
 }
 
@@ -93,6 +112,9 @@ __device__ __forceinline__ bool better(int sq, uint32_t iq, int si, uint32_t ii)
 {
     return sq > si || (sq == si && iq < ii);
 }
+
+// champion rounds: 32-bit priority key of a FAST hit, larger = better, never 0 (score 12..16, rank < 2^24)
+__device__ __forceinline__ uint32_t champ_key(uint32_t score, uint32_t idx) { return ((score - 11u) << 24) | (0xFFFFFFu - idx); }
 
 __device__ __forceinline__ bool within(uint32_t axy, uint32_t bxy, long long r2)
 {
@@ -136,6 +158,10 @@ __global__ __launch_bounds__(256) void k_nms_zero(NmsLayout L, unsigned char *ws
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c <= L.ncell) P.cell_fill[c] = 0;
     if (c < 16) P.counters[c] = 0;
+    if (L.champ) { // border cells stay {0,0} = "no champion"; the interior is rewritten every round
+        const int nch = L.cgw * (L.gh + 2 * L.R);
+        for (int i = c; i < nch; i += gridDim.x * 256) P.champ[i] = make_uint2(0u, 0u);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_nms_count(const uint32_t *__restrict__ raw_xy_all,
@@ -208,6 +234,33 @@ __global__ __launch_bounds__(256) void k_nms_bin_planes(const unsigned long long
     const uint32_t *segoff = segoff_all + (size_t)f * nseg;
     uint32_t count = 0;
     uint32_t pos = MODE ? P.cell_start[c] : 0u;
+    if (MODE == 2) {
+        // champion rounds: records of a cell in PRIORITY order (score descending, raster rank ascending), so
+        // the best undecided point of a cell is always the first undecided record of its run
+        const uint32_t first = pos;
+        for (int lev = 5; lev >= 1; lev--) {
+            for (int y = y0; y < y1; y++) {
+                const size_t si = (size_t)y * ntx + tx;
+                const ulonglong2 p01 = *reinterpret_cast<const ulonglong2 *>(seg + si * 4);
+                const unsigned long long b2 = seg[si * 4 + 2];
+                const unsigned long long any = p01.x | p01.y | b2;
+                if (!(any & cmask)) continue;
+                unsigned long long m = cmask & ((lev & 1) ? p01.x : ~p01.x) & ((lev & 2) ? p01.y : ~p01.y) & ((lev & 4) ? b2 : ~b2);
+                const uint32_t idx0 = segoff[si];
+                while (m) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t idx = idx0 + (uint32_t)__popcll(any & ((1ull << l) - 1ull)); // raster rank
+                    if (idx < (uint32_t)n_cap)
+                        P.rec[pos++] = make_uint4(((uint32_t)y << 16) | (uint32_t)(tx * 64 + l), (uint32_t)(lev + 11), idx, ST_UNDECIDED);
+                }
+            }
+        }
+        uint2 ch = make_uint2(0u, 0u);
+        if (pos > first) { const uint4 r0 = P.rec[first]; ch = make_uint2(champ_key(r0.y, r0.z), r0.x); }
+        P.champ[(cy + L.R) * L.cgw + cx + L.R] = ch;
+        return;
+    }
     for (int y = y0; y < y1; y++) {
         const size_t si = (size_t)y * ntx + tx;
         const ulonglong2 p01 = *reinterpret_cast<const ulonglong2 *>(seg + si * 4);
@@ -233,28 +286,42 @@ __global__ __launch_bounds__(256) void k_nms_bin_planes(const unsigned long long
     if (!MODE) P.cell_fill[c] = count;
 }
 
-// The 3x3-cell neighbourhood of cell (cx, cy) as three runs of records, one flat index space.
-struct Runs { uint32_t q0, q1, q2, l0, l1, l2, total; };
+// The (2R+1)^2-cell neighbourhood of cell (cx, cy) as up to 7 runs of records (one per cell row), one flat
+// index space.  All indexing below is compile-time after unrolling, so the arrays live in registers.
+constexpr int MAXRUN = 7;
+struct Runs { uint32_t q[MAXRUN], l[MAXRUN], total; };
 
 __device__ __forceinline__ Runs cell_runs(const NmsPtrs &P, const NmsLayout &L, int cx, int cy)
 {
     Runs R;
-    const int cx0 = cx > 0 ? cx - 1 : 0, cx1 = cx + 1 < L.gw ? cx + 1 : L.gw - 1;
-    auto run = [&](int yy, uint32_t &q, uint32_t &len) {
-        if (yy < 0 || yy >= L.gh) { q = 0; len = 0; return; }
-        q = P.cell_start[yy * L.gw + cx0];
-        len = P.cell_start[yy * L.gw + cx1 + 1] - q;
-    };
-    run(cy - 1, R.q0, R.l0);
-    run(cy, R.q1, R.l1);
-    run(cy + 1, R.q2, R.l2);
-    R.total = R.l0 + R.l1 + R.l2;
+    const int cx0 = cx - L.R > 0 ? cx - L.R : 0, cx1 = cx + L.R < L.gw ? cx + L.R : L.gw - 1;
+    R.total = 0;
+#pragma unroll
+    for (int j = 0; j < MAXRUN; j++) {
+        const int yy = cy - L.R + j;
+        uint32_t q = 0, len = 0;
+        if (j <= 2 * L.R && yy >= 0 && yy < L.gh) {
+            q = P.cell_start[yy * L.gw + cx0];
+            len = P.cell_start[yy * L.gw + cx1 + 1] - q;
+        }
+        R.q[j] = q; R.l[j] = len;
+        R.total += len;
+    }
     return R;
 }
 
 __device__ __forceinline__ uint32_t run_pos(const Runs &R, uint32_t fi)
 {
-    return fi < R.l0 ? R.q0 + fi : (fi < R.l0 + R.l1 ? R.q1 + (fi - R.l0) : R.q2 + (fi - R.l0 - R.l1));
+    uint32_t pos = 0;
+    bool done = false;
+#pragma unroll
+    for (int j = 0; j < MAXRUN; j++) {
+        const bool in = !done && fi < R.l[j];
+        pos = in ? R.q[j] + fi : pos;
+        done = done || in;
+        fi -= R.l[j]; // only meaningful while !done
+    }
+    return pos;
 }
 
 constexpr int NB_REG = 4; // neighbour records per lane and pass (256 neighbours)
@@ -345,6 +412,117 @@ __global__ __launch_bounds__(256) void k_nms_phase_a(NmsLayout L, int radius, in
         }
     }
     if (und_seen == 0 && lane == 0) P.cell_und[c] = 0; // everything here was decided by last round's suppression pass
+}
+
+// ---- champion rounds (L.champ): cells are small enough that any two points of a cell are within r, so in
+// every round only the best undecided point of a cell (its champion) can be locally best; every other
+// undecided point of the cell is beaten by its champion without a single distance test.
+//
+// k_nms_champ     one lane per cell: advance the cell's cursor past decided records (records are in priority
+//                 order) and publish {key, xy} of the champion in the padded champion grid;
+// k_nms_phase_c   one lane per cell: compare the champion with the (2R+1)^2-1 neighbouring champions
+//                 (coalesced 8-byte loads): a better champion within r beats it; no better champion at all
+//                 in the block accepts it (any better undecided point q within r would make the champion of
+//                 q's cell better still); only "better champion, but farther than r" needs the exact test
+//                 over the block's records, done by the whole wavefront for one such cell at a time.
+// The accepted set of a round is exactly the locally-best set of the plain formulation above.
+__global__ __launch_bounds__(256) void k_nms_champ(NmsLayout L, unsigned char *ws_all, size_t ws_stride)
+{
+    const int f = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= L.ncell) return;
+    NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
+    if (P.cell_und[c] == 0) return; // its grid entry is already {0,0}
+    uint32_t h = P.cell_fill[c];
+    const uint32_t e = P.cell_start[c + 1];
+    uint4 r = make_uint4(0, 0, 0, ST_SUPPRESSED);
+    while (h < e) {
+        r = P.rec[h];
+        if (r.w == ST_UNDECIDED) break;
+        h++;
+    }
+    const int cy = c / L.gw, cx = c - cy * L.gw;
+    P.cell_fill[c] = h;
+    if (h < e) {
+        P.champ[(cy + L.R) * L.cgw + cx + L.R] = make_uint2(champ_key(r.y, r.z), r.x);
+    } else {
+        P.champ[(cy + L.R) * L.cgw + cx + L.R] = make_uint2(0u, 0u);
+        P.cell_und[c] = 0;
+    }
+}
+
+template <int RR>
+__global__ __launch_bounds__(256) void k_nms_phase_c(NmsLayout L, int radius, int round, unsigned char *ws_all,
+                                                     size_t ws_stride)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
+    const bool incell = c < L.ncell;
+    const int cc = incell ? c : 0;
+    const int cy = cc / L.gw, cx = cc - cy * L.gw;
+    const uint2 *crow = P.champ + (size_t)(cy + RR) * L.cgw + cx + RR;
+    const uint2 me = *crow;
+    const bool live = incell && me.x != 0u;
+    if (!__any(live)) return;
+    const long long r2 = (long long)radius * (long long)radius;
+
+    bool beaten = false, far_better = false;
+#pragma unroll
+    for (int dy = -RR; dy <= RR; dy++) {
+        uint2 o[2 * RR + 1];
+#pragma unroll
+        for (int dx = -RR; dx <= RR; dx++) o[dx + RR] = crow[dy * L.cgw + dx];
+#pragma unroll
+        for (int dx = -RR; dx <= RR; dx++) {
+            if (dx == 0 && dy == 0) continue;
+            const bool b = o[dx + RR].x > me.x;
+            const bool w = within(o[dx + RR].y, me.y, r2);
+            beaten = beaten || (b && w);
+            far_better = far_better || (b && !w);
+        }
+    }
+    bool accept = live && !beaten && !far_better;
+
+    // exact test for the undecided cases, one centre at a time over the whole wavefront
+    unsigned long long todo = __ballot(live && !beaten && far_better);
+    while (todo) {
+        const int k = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t ckey = (uint32_t)__shfl((int)me.x, k), cxy = (uint32_t)__shfl((int)me.y, k);
+        const int kx = __shfl(cx, k), ky = __shfl(cy, k);
+        const Runs R = cell_runs(P, L, kx, ky);
+        bool h = false;
+        for (uint32_t nb0 = 0; nb0 < R.total; nb0 += 64 * NB_REG) {
+            uint4 nb[NB_REG];
+#pragma unroll
+            for (int j = 0; j < NB_REG; j++) {
+                const uint32_t fi = nb0 + j * 64 + lane;
+                nb[j] = fi < R.total ? P.rec[run_pos(R, fi)] : make_uint4(0, 0, 0, ST_SUPPRESSED);
+            }
+#pragma unroll
+            for (int j = 0; j < NB_REG; j++) {
+                // a point accepted earlier in THIS phase (NEW) was undecided when the round began; the centre
+                // itself has key == ckey and drops out of the strict comparison
+                h = h || ((nb[j].w == ST_UNDECIDED || nb[j].w == ST_NEW) && champ_key(nb[j].y, nb[j].z) > ckey &&
+                          within(nb[j].x, cxy, r2));
+            }
+            if (__any(h)) break;
+        }
+        if (!__any(h) && lane == k) accept = true;
+    }
+
+    const unsigned long long acc = __ballot(accept);
+    if (acc) { // nobody better within r: accept, and queue for this round's suppression pass
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&P.counters[round & 1], (uint32_t)__popcll(acc));
+        base = (uint32_t)__shfl((int)base, 0);
+        if (accept) {
+            const uint32_t p = P.cell_fill[c]; // the champion's record
+            *rec_state(P.rec, p) = ST_NEW;
+            P.listA[base + (uint32_t)__popcll(acc & ((1ull << lane) - 1ull))] = p;
+        }
+    }
 }
 
 // Phase B, one wavefront per NEWLY accepted point (a few thousand per frame over all rounds): retire
@@ -550,7 +728,7 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
 
 } // namespace
 
-size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap) { return nms_layout(W, H, radius, n_cap).total; }
+size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap, bool planes) { return nms_layout(W, H, radius, n_cap, planes).total; }
 
 void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw, int F,
                     int n_cap, int W, int H, int radius, void *wsv, size_t ws_stride, uint32_t *order,
@@ -558,22 +736,30 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
 {
     if (F <= 0) return;
     unsigned char *ws = reinterpret_cast<unsigned char *>(wsv);
-    const NmsLayout L = nms_layout(W, H, radius, n_cap);
+    const bool have_planes = seg && segoff;
+    const NmsLayout L = nms_layout(W, H, radius, n_cap, have_planes);
     const bool rounds = radius >= 0;
     const dim3 pgrid((n_cap + 255) / 256, F);
     const dim3 cgrid((L.ncell + 3) / 4, F);
     if (rounds) {
-        const bool planes = seg && segoff && (L.cs == 16 || L.cs == 32 || L.cs == 64);
+        const bool planes = have_planes && (L.cs == 8 || L.cs == 16 || L.cs == 32 || L.cs == 64);
         const dim3 bgrid((L.ncell + 255) / 256, F);
         const int ntx = (W + 63) / 64;
         hipLaunchKernelGGL(k_nms_zero, dim3((L.ncell + 256) / 256, F), dim3(256), 0, s, L, ws, ws_stride);
         if (planes) hipLaunchKernelGGL(k_nms_bin_planes<0>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
         else hipLaunchKernelGGL(k_nms_count, pgrid, dim3(256), 0, s, raw_xy, n_raw, n_cap, L, ws, ws_stride);
         hipLaunchKernelGGL(k_nms_cellscan, dim3(F), dim3(NT), 0, s, L, ws, ws_stride);
-        if (planes) hipLaunchKernelGGL(k_nms_bin_planes<1>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
+        if (L.champ) hipLaunchKernelGGL(k_nms_bin_planes<2>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
+        else if (planes) hipLaunchKernelGGL(k_nms_bin_planes<1>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
         else hipLaunchKernelGGL(k_nms_scatter, pgrid, dim3(256), 0, s, raw_xy, raw_score, n_raw, n_cap, L, ws, ws_stride);
         for (int r = 0; r < WIDE_ROUNDS; r++) {
-            hipLaunchKernelGGL(k_nms_phase_a, cgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
+            if (L.champ) {
+                if (r > 0) hipLaunchKernelGGL(k_nms_champ, bgrid, dim3(256), 0, s, L, ws, ws_stride);
+                if (L.R <= 2) hipLaunchKernelGGL(k_nms_phase_c<2>, bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
+                else hipLaunchKernelGGL(k_nms_phase_c<3>, bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
+            } else {
+                hipLaunchKernelGGL(k_nms_phase_a, cgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
+            }
             hipLaunchKernelGGL(k_nms_push, dim3(r == 0 ? 256 : 64, F), dim3(256), 0, s, L, radius, r, ws, ws_stride);
         }
     }

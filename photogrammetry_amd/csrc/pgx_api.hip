@@ -74,7 +74,7 @@ int enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_
     HIPCHK(c, c->ws_segoff.ensure((size_t)F * nseg * 4));
     HIPCHK(c, c->ws_rawxy.ensure((size_t)F * raw_cap * 4));
     HIPCHK(c, c->ws_rawscore.ensure((size_t)F * raw_cap * 4));
-    const size_t nms_stride = pgx_nms_ws_bytes(W, H, c->radius, raw_cap);
+    const size_t nms_stride = pgx_nms_ws_bytes(W, H, c->radius, raw_cap, true);
     HIPCHK(c, c->ws_nms.ensure((size_t)F * nms_stride));
     HIPCHK(c, c->ws_order.ensure((size_t)F * cap * 4));
     HIPCHK(c, c->ws_nkept.ensure((size_t)F * 4));
@@ -359,7 +359,7 @@ int pgx_nms(pgx_ctx *c, const pgx_keypoint *kps, int n, int W, int H, int32_t *o
         xy[i] = ((uint32_t)kps[i].y << 16) | (uint32_t)kps[i].x;
         sc[i] = kps[i].fast_score;
     }
-    const size_t wsb = pgx_nms_ws_bytes(W, H, c->radius, n);
+    const size_t wsb = pgx_nms_ws_bytes(W, H, c->radius, n, false);
     HIPCHK(c, c->st_a.ensure((size_t)n * 4));
     HIPCHK(c, c->st_b.ensure((size_t)n * 4));
     HIPCHK(c, c->st_c.ensure((size_t)n * 4));

@@ -147,7 +147,7 @@ void pgx_launch_fast(hipStream_t s, const float *gray, int F, int W, int H, floa
                      int32_t *raw_score /*[F][raw_cap]*/, int raw_cap, int *status);
 
 // k_nms.hip
-size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap);  // per frame
+size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap, bool planes);  // per frame; planes: the fused detect path
 void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw,
                     int F, int n_cap, int W, int H, int radius, void *ws, size_t ws_stride,
                     uint32_t *order /*[F][kp_cap]*/, int32_t *n_kept /*[F]*/, int kp_cap, int *status,
