@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[1]): 1920x1080 RGBA64 frame pairs, dewarp -> gra
 detect -> NMS (r=16) -> BRIEF-256 -> all-pairs Hamming match with the reference's greedy
 assignment, 4096 keypoints per frame (lists truncated to their first 4096 in NMS order: a harness
 choice, the reference has no cap).  One "step" = one batch of B independent image pairs per GPU
-(--pairs-per-step, default 32), frames already resident in HBM; value = sum over pairs of N1*N2
+(--pairs-per-step, default 64), frames already resident in HBM; value = sum over pairs of N1*N2
 divided by the WHOLE step time (detect + match), max over ranks.  Weak scaling: every rank
 processes its own B pairs; the per-pair match lists are all-gathered (RCCL) once after the timed
 region's last step -- they are the input of the (host-side) track graph.
@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-step", type=int, default=32)
+    ap.add_argument("--pairs-per-step", type=int, default=64)
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dewarp", action="store_true")

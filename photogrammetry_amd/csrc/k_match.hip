@@ -328,34 +328,44 @@ __global__ __launch_bounds__(256) void k_tail_fill(uint32_t *ws, const uint32_t 
     const int ystride = (ny + 7) & ~7;
     uint16_t *mat = p.dcache + (side ? (size_t)PGX_TAIL_MAX * PGX_TAIL_MAX : 0);
     uint32_t *bestout = side ? p.colkey : p.rowkey;
-    const int i = blockIdx.x * 4 + wv;
-    if (i >= nx) return; // wave-uniform
-    const uint4 a0 = *reinterpret_cast<const uint4 *>(dX + (size_t)xl[i] * 8);
-    const uint4 a1 = *reinterpret_cast<const uint4 *>(dX + (size_t)xl[i] * 8 + 4);
-    uint32_t best = PGX_KEY_NONE;
-    for (int j2 = lane * 2; j2 < ystride; j2 += 128) {
-        uint32_t d0 = 0xFFFFu, d1 = 0xFFFFu;
-        if (j2 < ny) {
-            const uint32_t *b = dY + (size_t)yl[j2] * 8;
-            const uint4 b0 = *reinterpret_cast<const uint4 *>(b), b1 = *reinterpret_cast<const uint4 *>(b + 4);
-            d0 = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
-                 __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
-            const uint32_t key = (d0 << PGX_IDX_BITS) | (uint32_t)j2;
-            best = key < best ? key : best;
-        }
-        if (j2 + 1 < ny) {
-            const uint32_t *b = dY + (size_t)yl[j2 + 1] * 8;
-            const uint4 b0 = *reinterpret_cast<const uint4 *>(b), b1 = *reinterpret_cast<const uint4 *>(b + 4);
-            d1 = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
-                 __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
-            const uint32_t key = (d1 << PGX_IDX_BITS) | (uint32_t)(j2 + 1);
-            best = key < best ? key : best;
-        }
-        *reinterpret_cast<uint32_t *>(mat + (size_t)i * ystride + j2) = d0 | (d1 << 16);
-    }
-    best = wave_min_u32(best);
-    if (lane == 0) bestout[i] = best;
+    // four matrix rows per wavefront: every gathered column descriptor is used four times
+    const int i0 = (blockIdx.x * 4 + wv) * 4;
     if (blockIdx.x == 0 && side == 0 && threadIdx.x == 0) p.cnt[CNT_FILLED] = 1;
+    if (i0 >= nx) return; // wave-uniform
+    uint4 a0[4], a1[4];
+    uint32_t best[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int i = i0 + u < nx ? i0 + u : nx - 1; // duplicates of the last row are computed and dropped
+        a0[u] = *reinterpret_cast<const uint4 *>(dX + (size_t)xl[i] * 8);
+        a1[u] = *reinterpret_cast<const uint4 *>(dX + (size_t)xl[i] * 8 + 4);
+        best[u] = PGX_KEY_NONE;
+    }
+    for (int j2 = lane * 2; j2 < ystride; j2 += 128) {
+        const bool v0 = j2 < ny, v1 = j2 + 1 < ny;
+        const uint32_t *bp0 = dY + (size_t)yl[v0 ? j2 : 0] * 8, *bp1 = dY + (size_t)yl[v1 ? j2 + 1 : 0] * 8;
+        const uint4 b00 = *reinterpret_cast<const uint4 *>(bp0), b01 = *reinterpret_cast<const uint4 *>(bp0 + 4);
+        const uint4 b10 = *reinterpret_cast<const uint4 *>(bp1), b11 = *reinterpret_cast<const uint4 *>(bp1 + 4);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint32_t d0 = __popc(a0[u].x ^ b00.x) + __popc(a0[u].y ^ b00.y) + __popc(a0[u].z ^ b00.z) + __popc(a0[u].w ^ b00.w) +
+                          __popc(a1[u].x ^ b01.x) + __popc(a1[u].y ^ b01.y) + __popc(a1[u].z ^ b01.z) + __popc(a1[u].w ^ b01.w);
+            uint32_t d1 = __popc(a0[u].x ^ b10.x) + __popc(a0[u].y ^ b10.y) + __popc(a0[u].z ^ b10.z) + __popc(a0[u].w ^ b10.w) +
+                          __popc(a1[u].x ^ b11.x) + __popc(a1[u].y ^ b11.y) + __popc(a1[u].z ^ b11.z) + __popc(a1[u].w ^ b11.w);
+            const uint32_t k0 = v0 ? ((d0 << PGX_IDX_BITS) | (uint32_t)j2) : PGX_KEY_NONE;
+            const uint32_t k1 = v1 ? ((d1 << PGX_IDX_BITS) | (uint32_t)(j2 + 1)) : PGX_KEY_NONE;
+            best[u] = k0 < best[u] ? k0 : best[u];
+            best[u] = k1 < best[u] ? k1 : best[u];
+            d0 = v0 ? d0 : 0xFFFFu;
+            d1 = v1 ? d1 : 0xFFFFu;
+            if (i0 + u < nx) *reinterpret_cast<uint32_t *>(mat + (size_t)(i0 + u) * ystride + j2) = d0 | (d1 << 16);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t b = wave_min_u32(best[u]);
+        if (lane == 0 && i0 + u < nx) bestout[i0 + u] = b;
+    }
 }
 
 template <int WORDS>
@@ -645,7 +655,7 @@ void pgx_launch_match(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const
     }
     if (plan.words == 8) {
         ProfScope ps(ctx, "tail_fill");
-        hipLaunchKernelGGL(k_tail_fill, dim3(PGX_TAIL_MAX / 4, 2, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
+        hipLaunchKernelGGL(k_tail_fill, dim3(PGX_TAIL_MAX / 16, 2, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
     }
     {
         ProfScope ps(ctx, "match_finish");

@@ -24,6 +24,7 @@
 //        sorts the accepted points (bitonic, LDS) and writes the order.
 // Integer work on L2-resident data (a few MB per frame); latency/issue-bound, not HBM-bound.
 #include "pgx_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -238,24 +239,47 @@ __global__ __launch_bounds__(256) void k_nms_bin_planes(const unsigned long long
         // champion rounds: records of a cell in PRIORITY order (score descending, raster rank ascending), so
         // the best undecided point of a cell is always the first undecided record of its run
         const uint32_t first = pos;
-        for (int lev = 5; lev >= 1; lev--) {
-            for (int y = y0; y < y1; y++) {
-                const size_t si = (size_t)y * ntx + tx;
-                const ulonglong2 p01 = *reinterpret_cast<const ulonglong2 *>(seg + si * 4);
-                const unsigned long long b2 = seg[si * 4 + 2];
-                const unsigned long long any = p01.x | p01.y | b2;
-                if (!(any & cmask)) continue;
-                unsigned long long m = cmask & ((lev & 1) ? p01.x : ~p01.x) & ((lev & 2) ? p01.y : ~p01.y) & ((lev & 4) ? b2 : ~b2);
-                const uint32_t idx0 = segoff[si];
-                while (m) {
-                    const int l = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const uint32_t idx = idx0 + (uint32_t)__popcll(any & ((1ull << l) - 1ull)); // raster rank
-                    if (idx < (uint32_t)n_cap)
-                        P.rec[pos++] = make_uint4(((uint32_t)y << 16) | (uint32_t)(tx * 64 + l), (uint32_t)(lev + 11), idx, ST_UNDECIDED);
-                }
+        // pass 1: hits per score level -> start of each level's sub-run; pass 2: place every hit of a row
+        uint32_t n5 = 0, n4 = 0, n3 = 0, n2 = 0;
+        // hits past the raw capacity are dropped everywhere (PGX_E_CAPACITY is raised): keep the first
+        // n_cap - idx0 hits of a row slice, exactly what the count pass kept
+        auto cut = [&](unsigned long long m, uint32_t idx0) {
+            const uint32_t room = idx0 < (uint32_t)n_cap ? (uint32_t)n_cap - idx0 : 0u;
+            while ((uint32_t)__popcll(m) > room) m &= ~(1ull << (63 - __builtin_clzll(m)));
+            return m;
+        };
+        for (int y = y0; y < y1; y++) {
+            const size_t si = (size_t)y * ntx + tx;
+            const ulonglong2 p01 = *reinterpret_cast<const ulonglong2 *>(seg + si * 4);
+            const unsigned long long b2 = seg[si * 4 + 2];
+            const unsigned long long any = p01.x | p01.y | b2;
+            if (!(any & cmask)) continue;
+            const unsigned long long m = cut(any & cmask, segoff[si] + (uint32_t)__popcll(any & ((1ull << bo) - 1ull)));
+            n5 += (uint32_t)__popcll(m & b2 & p01.x);            // codes: 5 = 101, 4 = 100, 3 = 011, 2 = 010, 1 = 001
+            n4 += (uint32_t)__popcll(m & b2 & ~p01.x);
+            n3 += (uint32_t)__popcll(m & ~b2 & p01.y & p01.x);
+            n2 += (uint32_t)__popcll(m & ~b2 & p01.y & ~p01.x);
+        }
+        uint32_t q5 = first, q4 = q5 + n5, q3 = q4 + n4, q2 = q3 + n3, q1 = q2 + n2;
+        for (int y = y0; y < y1; y++) {
+            const size_t si = (size_t)y * ntx + tx;
+            const ulonglong2 p01 = *reinterpret_cast<const ulonglong2 *>(seg + si * 4);
+            const unsigned long long b2 = seg[si * 4 + 2];
+            const unsigned long long any = p01.x | p01.y | b2;
+            if (!(any & cmask)) continue;
+            uint32_t idx = segoff[si] + (uint32_t)__popcll(any & ((1ull << bo) - 1ull)); // raster rank of the first hit here
+            unsigned long long m = cut(any & cmask, idx);
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const int code = (int)((p01.x >> l) & 1ull) | ((int)((p01.y >> l) & 1ull) << 1) | ((int)((b2 >> l) & 1ull) << 2);
+                const uint32_t at = code == 5 ? q5 : (code == 4 ? q4 : (code == 3 ? q3 : (code == 2 ? q2 : q1)));
+                q5 += code == 5; q4 += code == 4; q3 += code == 3; q2 += code == 2; q1 += code == 1;
+                P.rec[at] = make_uint4(((uint32_t)y << 16) | (uint32_t)(tx * 64 + l), (uint32_t)(code + 11), idx, ST_UNDECIDED);
+                idx++;
             }
         }
+        pos = q1;
         uint2 ch = make_uint2(0u, 0u);
         if (pos > first) { const uint4 r0 = P.rec[first]; ch = make_uint2(champ_key(r0.y, r0.z), r0.x); }
         P.champ[(cy + L.R) * L.cgw + cx + L.R] = ch;
@@ -683,7 +707,59 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
     }
     const uint32_t nacc = sh_cnt;
     const uint32_t n2p = [](uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }(nacc > 1 ? nacc : 1);
-    if (n2p <= SORT_LDS_MAX) {
+    const uint32_t nw = ((uint32_t)n + 63u) / 64u * 2u;        // 32-bit bitmap words for the raster ranks of one score level
+    if (L.champ && radius >= 0 && nw <= SORT_LDS_MAX * 2) {
+        // FAST scores are 12..16 and the input index is the raster rank, so the output order is "level by
+        // level, rank ascending": one bitmap of ranks per level in LDS, a popcount scan, and every set bit
+        // knows its place.  No comparison sort.
+        uint32_t *bm = reinterpret_cast<uint32_t *>(lds_keys);
+        const uint32_t lp = (SORT_LDS_MAX * 2) / nw < 5u ? (SORT_LDS_MAX * 2) / nw : 5u; // levels per pass
+        const int lane = tid & 63, wv = tid >> 6;
+        uint32_t base = 0;
+        for (int lev_hi = 16; lev_hi >= 12; lev_hi -= (int)lp) {
+            const uint32_t tw = lp * nw;
+            __syncthreads();
+            for (uint32_t i = tid; i < tw; i += NT) bm[i] = 0u;
+            __syncthreads();
+            for (uint32_t i = tid; i < nacc; i += NT) {
+                const unsigned long long k = P.sortkeys[i];
+                const int sc = (int)(~(uint32_t)(k >> 32) ^ 0x80000000u);
+                const uint32_t idx = (uint32_t)k;
+                const int slot = lev_hi - sc;
+                if (slot >= 0 && slot < (int)lp && sc >= 12) atomicOr(&bm[(uint32_t)slot * nw + (idx >> 5)], 1u << (idx & 31u));
+            }
+            __syncthreads();
+            // each wavefront owns a contiguous span of words (rows of 64, lanes on consecutive words)
+            const uint32_t rows = (tw + 63u) / 64u, rpw = (rows + NT / 64 - 1) / (NT / 64);
+            const uint32_t r0 = (uint32_t)wv * rpw, r1 = r0 + rpw < rows ? r0 + rpw : rows;
+            uint32_t cnt = 0;
+            for (uint32_t r = r0; r < r1; r++) { const uint32_t w = r * 64u + lane; cnt += w < tw ? (uint32_t)__popc(bm[w]) : 0u; }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
+            if (lane == 0) wsum[wv] = cnt;
+            __syncthreads();
+            uint32_t run = base, tot = 0;
+            for (int w = 0; w < NT / 64; w++) { const uint32_t v = wsum[w]; if (w < wv) run += v; tot += v; }
+            for (uint32_t r = r0; r < r1; r++) {
+                const uint32_t w = r * 64u + lane;
+                uint32_t bits = w < tw ? bm[w] : 0u;
+                const uint32_t c = (uint32_t)__popc(bits);
+                uint32_t incl = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += t; }
+                uint32_t o = run + incl - c;
+                const uint32_t wl = w % nw; // word inside its level
+                while (bits) {
+                    const int b = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    if (o < (uint32_t)kp_cap) order[o] = wl * 32u + (uint32_t)b;
+                    o++;
+                }
+                run += (uint32_t)__shfl((int)incl, 63);
+            }
+            base += tot;
+        }
+    } else if (n2p <= SORT_LDS_MAX) {
         for (uint32_t i = tid; i < n2p; i += NT) lds_keys[i] = i < nacc ? P.sortkeys[i] : ~0ull;
         bitonic_sort_u64(lds_keys, n2p);
         for (uint32_t i = tid; i < nacc && i < (uint32_t)kp_cap; i += NT) order[i] = (uint32_t)lds_keys[i];
@@ -752,7 +828,8 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
         if (L.champ) hipLaunchKernelGGL(k_nms_bin_planes<2>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
         else if (planes) hipLaunchKernelGGL(k_nms_bin_planes<1>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
         else hipLaunchKernelGGL(k_nms_scatter, pgrid, dim3(256), 0, s, raw_xy, raw_score, n_raw, n_cap, L, ws, ws_stride);
-        for (int r = 0; r < WIDE_ROUNDS; r++) {
+        static const int wide_rounds = [] { const char *e = getenv("PGX_NMS_ROUNDS"); int v = e ? atoi(e) : WIDE_ROUNDS; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+        for (int r = 0; r < wide_rounds; r++) {
             if (L.champ) {
                 if (r > 0) hipLaunchKernelGGL(k_nms_champ, bgrid, dim3(256), 0, s, L, ws, ws_stride);
                 if (L.R <= 2) hipLaunchKernelGGL(k_nms_phase_c<2>, bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
