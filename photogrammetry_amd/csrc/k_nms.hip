@@ -107,7 +107,9 @@ __device__ __forceinline__ NmsPtrs nms_ptrs(unsigned char *ws, const NmsLayout &
 __device__ __forceinline__ uint32_t *rec_state(uint4 *rec, uint32_t p) { return reinterpret_cast<uint32_t *>(rec + p) + 3; }
 
 // 0 undecided, 1 accepted in the running round, 2 suppressed, 3 accepted earlier
-enum : uint32_t { ST_UNDECIDED = 0, ST_NEW = 1, ST_SUPPRESSED = 2, ST_ACCEPTED = 3 };
+// champion rounds stamp an accepted point with ST_ACC_ROUND + round: "accepted earlier in the running phase" (it
+// was undecided when the round began) can then be told from "accepted in an earlier round" without a fix-up pass
+enum : uint32_t { ST_UNDECIDED = 0, ST_NEW = 1, ST_SUPPRESSED = 2, ST_ACCEPTED = 3, ST_ACC_ROUND = 4 };
 
 __device__ __forceinline__ bool better(int sq, uint32_t iq, int si, uint32_t ii)
 {
@@ -120,6 +122,13 @@ __device__ __forceinline__ uint32_t champ_key(uint32_t score, uint32_t idx) { re
 __device__ __forceinline__ bool within(uint32_t axy, uint32_t bxy, long long r2)
 {
     const long long dx = (int)(axy & 0xFFFFu) - (int)(bxy & 0xFFFFu), dy = (int)(axy >> 16) - (int)(bxy >> 16);
+    return dx * dx + dy * dy <= r2;
+}
+
+// same test for points known to be a few cells apart (champion rounds: |d| <= 7 * 64, r <= 192)
+__device__ __forceinline__ bool within_near(uint32_t axy, uint32_t bxy, int r2)
+{
+    const int dx = (int)(axy & 0xFFFFu) - (int)(bxy & 0xFFFFu), dy = (int)(axy >> 16) - (int)(bxy >> 16);
     return dx * dx + dy * dy <= r2;
 }
 
@@ -460,11 +469,19 @@ __global__ __launch_bounds__(256) void k_nms_champ(NmsLayout L, unsigned char *w
     uint32_t h = P.cell_fill[c];
     const uint32_t e = P.cell_start[c + 1];
     uint4 r = make_uint4(0, 0, 0, ST_SUPPRESSED);
-    while (h < e) {
-        r = P.rec[h];
-        if (r.w == ST_UNDECIDED) break;
-        h++;
+    while (h < e) { // four records per trip: the walk is a chain of dependent L2 round trips otherwise
+        const uint4 none = make_uint4(0, 0, 0, ST_SUPPRESSED);
+        const uint4 r0 = P.rec[h];
+        const uint4 r1 = h + 1 < e ? P.rec[h + 1] : none;
+        const uint4 r2 = h + 2 < e ? P.rec[h + 2] : none;
+        const uint4 r3 = h + 3 < e ? P.rec[h + 3] : none;
+        if (r0.w == ST_UNDECIDED) { r = r0; break; }
+        if (r1.w == ST_UNDECIDED) { r = r1; h += 1; break; }
+        if (r2.w == ST_UNDECIDED) { r = r2; h += 2; break; }
+        if (r3.w == ST_UNDECIDED) { r = r3; h += 3; break; }
+        h += 4;
     }
+    if (h > e) h = e;
     const int cy = c / L.gw, cx = c - cy * L.gw;
     P.cell_fill[c] = h;
     if (h < e) {
@@ -489,7 +506,7 @@ __global__ __launch_bounds__(256) void k_nms_phase_c(NmsLayout L, int radius, in
     const uint2 me = *crow;
     const bool live = incell && me.x != 0u;
     if (!__any(live)) return;
-    const long long r2 = (long long)radius * (long long)radius;
+    const int r2 = radius * radius;
 
     bool beaten = false, far_better = false;
 #pragma unroll
@@ -501,50 +518,72 @@ __global__ __launch_bounds__(256) void k_nms_phase_c(NmsLayout L, int radius, in
         for (int dx = -RR; dx <= RR; dx++) {
             if (dx == 0 && dy == 0) continue;
             const bool b = o[dx + RR].x > me.x;
-            const bool w = within(o[dx + RR].y, me.y, r2);
+            const bool w = within_near(o[dx + RR].y, me.y, r2);
             beaten = beaten || (b && w);
             far_better = far_better || (b && !w);
         }
     }
     bool accept = live && !beaten && !far_better;
 
-    // exact test for the undecided cases, one centre at a time over the whole wavefront
-    unsigned long long todo = __ballot(live && !beaten && far_better);
+    // One centre at a time over the whole wavefront (lanes = the records of its (2R+1)^2 block):
+    //   - the undecided cases get the exact test;
+    //   - every accepted centre suppresses its neighbours right away.  Doing that inside the phase is safe:
+    //     a point within r of an accepted one can never be accepted itself, so retiring it early only stops
+    //     it from holding up others; readers that still see it undecided are merely conservative.
+    const unsigned long long deep = __ballot(live && !beaten && far_better);
+    unsigned long long todo = deep | __ballot(accept);
+    unsigned long long acc = 0;
     while (todo) {
         const int k = __builtin_ctzll(todo);
         todo &= todo - 1;
         const uint32_t ckey = (uint32_t)__shfl((int)me.x, k), cxy = (uint32_t)__shfl((int)me.y, k);
         const int kx = __shfl(cx, k), ky = __shfl(cy, k);
         const Runs R = cell_runs(P, L, kx, ky);
-        bool h = false;
+        if ((deep >> k) & 1ull) {
+            bool h = false;
+            for (uint32_t nb0 = 0; nb0 < R.total; nb0 += 64 * NB_REG) {
+                uint4 nb[NB_REG];
+#pragma unroll
+                for (int j = 0; j < NB_REG; j++) {
+                    const uint32_t fi = nb0 + j * 64 + lane;
+                    nb[j] = fi < R.total ? P.rec[run_pos(R, fi)] : make_uint4(0, 0, 0, ST_SUPPRESSED);
+                }
+#pragma unroll
+                for (int j = 0; j < NB_REG; j++) {
+                    // a point accepted earlier in THIS phase (stamped with this round) was undecided when the
+                    // round began; the centre itself has key == ckey and drops out of the strict comparison
+                    h = h || ((nb[j].w == ST_UNDECIDED || nb[j].w == ST_ACC_ROUND + (uint32_t)round) &&
+                              champ_key(nb[j].y, nb[j].z) > ckey && within_near(nb[j].x, cxy, r2));
+                }
+                if (__any(h)) break;
+            }
+            if (__any(h)) continue; // beaten: stays undecided
+        }
+        acc |= 1ull << k;
         for (uint32_t nb0 = 0; nb0 < R.total; nb0 += 64 * NB_REG) {
             uint4 nb[NB_REG];
+            uint32_t nq[NB_REG];
 #pragma unroll
             for (int j = 0; j < NB_REG; j++) {
                 const uint32_t fi = nb0 + j * 64 + lane;
-                nb[j] = fi < R.total ? P.rec[run_pos(R, fi)] : make_uint4(0, 0, 0, ST_SUPPRESSED);
+                nq[j] = fi < R.total ? run_pos(R, fi) : 0u;
+                nb[j] = fi < R.total ? P.rec[nq[j]] : make_uint4(0, 0, 0, ST_SUPPRESSED);
             }
 #pragma unroll
-            for (int j = 0; j < NB_REG; j++) {
-                // a point accepted earlier in THIS phase (NEW) was undecided when the round began; the centre
-                // itself has key == ckey and drops out of the strict comparison
-                h = h || ((nb[j].w == ST_UNDECIDED || nb[j].w == ST_NEW) && champ_key(nb[j].y, nb[j].z) > ckey &&
-                          within(nb[j].x, cxy, r2));
-            }
-            if (__any(h)) break;
+            for (int j = 0; j < NB_REG; j++) // the centre itself: key == ckey, skipped
+                if (nb[j].w == ST_UNDECIDED && champ_key(nb[j].y, nb[j].z) != ckey && within_near(nb[j].x, cxy, r2))
+                    *rec_state(P.rec, nq[j]) = ST_SUPPRESSED;
         }
-        if (!__any(h) && lane == k) accept = true;
     }
 
-    const unsigned long long acc = __ballot(accept);
-    if (acc) { // nobody better within r: accept, and queue for this round's suppression pass
+    if (acc) { // stamp the accepted champions and emit their sort keys
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&P.counters[round & 1], (uint32_t)__popcll(acc));
+        if (lane == 0) base = atomicAdd(&P.counters[2], (uint32_t)__popcll(acc));
         base = (uint32_t)__shfl((int)base, 0);
-        if (accept) {
-            const uint32_t p = P.cell_fill[c]; // the champion's record
-            *rec_state(P.rec, p) = ST_NEW;
-            P.listA[base + (uint32_t)__popcll(acc & ((1ull << lane) - 1ull))] = p;
+        if ((acc >> lane) & 1ull) {
+            *rec_state(P.rec, P.cell_fill[c]) = ST_ACC_ROUND + (uint32_t)round; // the champion's record
+            P.sortkeys[base + (uint32_t)__popcll(acc & ((1ull << lane) - 1ull))] =
+                sort_key((int)(me.x >> 24) + 11, 0xFFFFFFu - (me.x & 0xFFFFFFu));
         }
     }
 }
@@ -625,7 +664,7 @@ __device__ __forceinline__ bool tail_suppressed(const NmsPtrs &P, const NmsLayou
     const Runs R = cell_runs(P, L, cx, cy);
     for (uint32_t fi = 0; fi < R.total; fi++) {
         const uint4 o = P.rec[run_pos(R, fi)];
-        if ((o.w == ST_NEW || o.w == ST_ACCEPTED) && within(o.x, me.x, r2)) return true;
+        if ((o.w == ST_NEW || o.w >= ST_ACCEPTED) && within(o.x, me.x, r2)) return true;
     }
     return false;
 }
@@ -687,9 +726,14 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
                     P.sortkeys[atomicAdd(&P.counters[2], 1u)] = sort_key((int)me.y, me.z);
                 }
             }
+            const int n_prev = n_act;
             n_act = (int)sh_cnt;
             uint32_t *t = cur; cur = nxt; nxt = t;
             __syncthreads();
+            if (n_act >= n_prev) { // every round decides at least the best open point; anything else is a bug
+                if (tid == 0) atomicOr(status, (int)PGX_ST_INTERNAL);
+                break;
+            }
         }
     }
 
@@ -837,7 +881,7 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
             } else {
                 hipLaunchKernelGGL(k_nms_phase_a, cgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
             }
-            hipLaunchKernelGGL(k_nms_push, dim3(r == 0 ? 256 : 64, F), dim3(256), 0, s, L, radius, r, ws, ws_stride);
+            if (!L.champ) hipLaunchKernelGGL(k_nms_push, dim3(r == 0 ? 256 : 64, F), dim3(256), 0, s, L, radius, r, ws, ws_stride);
         }
     }
     static bool attr_set = false;

@@ -44,6 +44,7 @@ int decode_status(pgx_ctx *c, int bits)
     if (bits & PGX_ST_RAW_CAP)
         return fail(c, PGX_E_CAPACITY, "raw FAST hits exceed max_raw_per_frame (pgx_set_capacity)");
     if (bits & PGX_ST_KP_CAP) return fail(c, PGX_E_CAPACITY, "NMS survivors exceed the output capacity");
+    if (bits & PGX_ST_INTERNAL) return fail(c, PGX_E_HIP, "internal error: a device-side loop stopped without progress");
     return PGX_OK;
 }
 

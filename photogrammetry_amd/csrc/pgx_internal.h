@@ -17,6 +17,7 @@
 #define PGX_ST_RAW_CAP    2u
 #define PGX_ST_KP_CAP     4u
 #define PGX_ST_EMPTY_SET  8u
+#define PGX_ST_INTERNAL   16u  /* a device loop made no progress (a bug, never an input property) */
 
 // key = (distance << PGX_IDX_BITS) | index ; limits: index < 2^20, distance < 2^12
 #define PGX_IDX_BITS 20
