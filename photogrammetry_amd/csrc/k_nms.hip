@@ -242,81 +242,103 @@ __global__ __launch_bounds__(256) void k_nms_bin_planes(const unsigned long long
     const size_t nseg = (size_t)H * ntx;
     const unsigned long long *seg = seg_all + (size_t)f * nseg * 4;
     const uint32_t *segoff = segoff_all + (size_t)f * nseg;
-    uint32_t count = 0;
-    uint32_t pos = MODE ? P.cell_start[c] : 0u;
-    if (MODE == 2) {
-        // champion rounds: records of a cell in PRIORITY order (score descending, raster rank ascending), so
-        // the best undecided point of a cell is always the first undecided record of its run
-        const uint32_t first = pos;
-        // pass 1: hits per score level -> start of each level's sub-run; pass 2: place every hit of a row
-        uint32_t n5 = 0, n4 = 0, n3 = 0, n2 = 0;
-        // hits past the raw capacity are dropped everywhere (PGX_E_CAPACITY is raised): keep the first
-        // n_cap - idx0 hits of a row slice, exactly what the count pass kept
-        auto cut = [&](unsigned long long m, uint32_t idx0) {
-            const uint32_t room = idx0 < (uint32_t)n_cap ? (uint32_t)n_cap - idx0 : 0u;
-            while ((uint32_t)__popcll(m) > room) m &= ~(1ull << (63 - __builtin_clzll(m)));
-            return m;
-        };
-        for (int y = y0; y < y1; y++) {
-            const size_t si = (size_t)y * ntx + tx;
-            const ulonglong2 p01 = *reinterpret_cast<const ulonglong2 *>(seg + si * 4);
-            const unsigned long long b2 = seg[si * 4 + 2];
-            const unsigned long long any = p01.x | p01.y | b2;
-            if (!(any & cmask)) continue;
-            const unsigned long long m = cut(any & cmask, segoff[si] + (uint32_t)__popcll(any & ((1ull << bo) - 1ull)));
-            n5 += (uint32_t)__popcll(m & b2 & p01.x);            // codes: 5 = 101, 4 = 100, 3 = 011, 2 = 010, 1 = 001
-            n4 += (uint32_t)__popcll(m & b2 & ~p01.x);
-            n3 += (uint32_t)__popcll(m & ~b2 & p01.y & p01.x);
-            n2 += (uint32_t)__popcll(m & ~b2 & p01.y & ~p01.x);
+    // Rows go through in chunks of eight with all loads of a chunk issued before the first use (a load ->
+    // use loop is one L2 round trip per row, and a thread walks up to 64 rows).
+    constexpr int CH = 8;
+    ulonglong2 rp[CH];
+    unsigned long long rb[CH];
+    uint32_t rso[CH];
+    auto load_chunk = [&](int yc) {
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const bool ok = yc + i < y1;
+            const size_t si = (size_t)(ok ? yc + i : y0) * ntx + tx;
+            rp[i] = *reinterpret_cast<const ulonglong2 *>(seg + si * 4);
+            rb[i] = seg[si * 4 + 2];
+            rso[i] = segoff[si];
+            if (!ok) { rp[i] = make_ulonglong2(0ull, 0ull); rb[i] = 0ull; }
         }
-        uint32_t q5 = first, q4 = q5 + n5, q3 = q4 + n4, q2 = q3 + n3, q1 = q2 + n2;
-        for (int y = y0; y < y1; y++) {
-            const size_t si = (size_t)y * ntx + tx;
-            const ulonglong2 p01 = *reinterpret_cast<const ulonglong2 *>(seg + si * 4);
-            const unsigned long long b2 = seg[si * 4 + 2];
-            const unsigned long long any = p01.x | p01.y | b2;
+    };
+    // hits past the raw capacity are dropped everywhere (PGX_E_CAPACITY is raised): of a row slice whose
+    // first hit has raster rank idx0 only the first n_cap - idx0 hits exist
+    auto cut = [&](unsigned long long m, uint32_t idx0) {
+        const uint32_t room = idx0 < (uint32_t)n_cap ? (uint32_t)n_cap - idx0 : 0u;
+        while ((uint32_t)__popcll(m) > room) m &= ~(1ull << (63 - __builtin_clzll(m)));
+        return m;
+    };
+    const unsigned long long below = (1ull << bo) - 1ull;
+
+    if (MODE == 0) {
+        uint32_t count = 0;
+        for (int yc = y0; yc < y1; yc += CH) {
+            load_chunk(yc);
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const unsigned long long any = rp[i].x | rp[i].y | rb[i];
+                const uint32_t cnt = (uint32_t)__popcll(any & cmask);
+                const uint32_t idx0 = rso[i] + (uint32_t)__popcll(any & below);
+                const uint32_t room = idx0 < (uint32_t)n_cap ? (uint32_t)n_cap - idx0 : 0u;
+                count += cnt < room ? cnt : room;
+            }
+        }
+        P.cell_fill[c] = count;
+        return;
+    }
+
+    const uint32_t first = P.cell_start[c];
+    // MODE 1: raster order.  MODE 2 (champion rounds): PRIORITY order (score descending, raster rank ascending),
+    // so that the best undecided point of a cell is always the first undecided record of its run: pass 1 counts
+    // the hits per score level (-> start of each level's sub-run), pass 2 places every hit.
+    uint32_t q5 = first, q4 = first, q3 = first, q2 = first, q1 = first;
+    auto count_levels = [&]() {
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const unsigned long long any = rp[i].x | rp[i].y | rb[i];
             if (!(any & cmask)) continue;
-            uint32_t idx = segoff[si] + (uint32_t)__popcll(any & ((1ull << bo) - 1ull)); // raster rank of the first hit here
+            const unsigned long long m = cut(any & cmask, rso[i] + (uint32_t)__popcll(any & below));
+            // codes: 5 = 101, 4 = 100, 3 = 011, 2 = 010, 1 = 001; q_k accumulates the hits ABOVE level k
+            const uint32_t c5 = (uint32_t)__popcll(m & rb[i] & rp[i].x), c4 = (uint32_t)__popcll(m & rb[i] & ~rp[i].x);
+            const uint32_t c3 = (uint32_t)__popcll(m & ~rb[i] & rp[i].y & rp[i].x), c2 = (uint32_t)__popcll(m & ~rb[i] & rp[i].y & ~rp[i].x);
+            q4 += c5; q3 += c5 + c4; q2 += c5 + c4 + c3; q1 += c5 + c4 + c3 + c2;
+        }
+    };
+    auto place = [&](int yc) {
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const unsigned long long any = rp[i].x | rp[i].y | rb[i];
+            if (!(any & cmask)) continue;
+            uint32_t idx = rso[i] + (uint32_t)__popcll(any & below); // raster rank of the first hit here
             unsigned long long m = cut(any & cmask, idx);
             while (m) {
                 const int l = __builtin_ctzll(m);
                 m &= m - 1;
-                const int code = (int)((p01.x >> l) & 1ull) | ((int)((p01.y >> l) & 1ull) << 1) | ((int)((b2 >> l) & 1ull) << 2);
-                const uint32_t at = code == 5 ? q5 : (code == 4 ? q4 : (code == 3 ? q3 : (code == 2 ? q2 : q1)));
-                q5 += code == 5; q4 += code == 4; q3 += code == 3; q2 += code == 2; q1 += code == 1;
-                P.rec[at] = make_uint4(((uint32_t)y << 16) | (uint32_t)(tx * 64 + l), (uint32_t)(code + 11), idx, ST_UNDECIDED);
+                const int code = (int)((rp[i].x >> l) & 1ull) | ((int)((rp[i].y >> l) & 1ull) << 1) | ((int)((rb[i] >> l) & 1ull) << 2);
+                uint32_t at;
+                if (MODE == 2) {
+                    at = code == 5 ? q5 : (code == 4 ? q4 : (code == 3 ? q3 : (code == 2 ? q2 : q1)));
+                    q5 += code == 5; q4 += code == 4; q3 += code == 3; q2 += code == 2; q1 += code == 1;
+                } else {
+                    at = q1++;
+                }
+                P.rec[at] = make_uint4(((uint32_t)(yc + i) << 16) | (uint32_t)(tx * 64 + l), (uint32_t)(code + 11), idx, ST_UNDECIDED);
                 idx++;
             }
         }
-        pos = q1;
+    };
+    if (y1 - y0 <= CH) { // 8-pixel cells: one chunk serves both passes
+        load_chunk(y0);
+        if (MODE == 2) count_levels();
+        place(y0);
+    } else {
+        if (MODE == 2)
+            for (int yc = y0; yc < y1; yc += CH) { load_chunk(yc); count_levels(); }
+        for (int yc = y0; yc < y1; yc += CH) { load_chunk(yc); place(yc); }
+    }
+    if (MODE == 2) {
         uint2 ch = make_uint2(0u, 0u);
-        if (pos > first) { const uint4 r0 = P.rec[first]; ch = make_uint2(champ_key(r0.y, r0.z), r0.x); }
+        if (q1 > first) { const uint4 r0 = P.rec[first]; ch = make_uint2(champ_key(r0.y, r0.z), r0.x); }
         P.champ[(cy + L.R) * L.cgw + cx + L.R] = ch;
-        return;
     }
-    for (int y = y0; y < y1; y++) {
-        const size_t si = (size_t)y * ntx + tx;
-        const ulonglong2 p01 = *reinterpret_cast<const ulonglong2 *>(seg + si * 4);
-        const unsigned long long b2 = seg[si * 4 + 2];
-        const unsigned long long any = p01.x | p01.y | b2;
-        unsigned long long m = any & cmask;
-        if (!m) continue;
-        uint32_t idx = segoff[si] + (uint32_t)__popcll(any & ((1ull << bo) - 1ull)); // raster rank of the first hit here
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
-            if (idx < (uint32_t)n_cap) { // hits past the raw capacity are dropped everywhere (PGX_E_CAPACITY is raised)
-                if (MODE) {
-                    const int code = (int)((p01.x >> l) & 1ull) | ((int)((p01.y >> l) & 1ull) << 1) | ((int)((b2 >> l) & 1ull) << 2);
-                    P.rec[pos++] = make_uint4(((uint32_t)y << 16) | (uint32_t)(tx * 64 + l), (uint32_t)(code + 11), idx, ST_UNDECIDED);
-                } else {
-                    count++;
-                }
-            }
-            idx++;
-        }
-    }
-    if (!MODE) P.cell_fill[c] = count;
 }
 
 // The (2R+1)^2-cell neighbourhood of cell (cx, cy) as up to 7 runs of records (one per cell row), one flat
