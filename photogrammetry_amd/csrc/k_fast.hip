@@ -10,9 +10,11 @@
 //   so score = longest circular run of zero bits of S if that is >= 12, else none.
 //
 // HBM-bound: 4 B/px grey read (+ 0.5 B/px of ballot planes written).  Three launches:
-//   k_fast_planes   64x32-pixel tiles staged through LDS (halo 3); one wave per 8 tile rows,
-//                   one lane per pixel; per 64-pixel row segment three 64-bit ballots of the
-//                   score bits + the count -> seg[F][H][ntx][4]
+//   k_fast_planes   64x32-pixel tiles staged through LDS (halo 3).  Pass 1, one lane per pixel: the four
+//                   compass samples; pixels with at most one similar compass sample are queued in LDS.
+//                   Pass 2, one lane per QUEUED pixel (all lanes busy): the rest of the ring and the
+//                   run-length rule; score bits are OR-ed into the tile's three ballot planes in LDS.
+//                   Per 64-pixel row segment: three 64-bit planes + the count -> seg[F][H][ntx][4]
 //   k_seg_scan      one workgroup per frame: exclusive scan of the counts in (y, tx) order
 //                   = raster order; n_raw[f]
 //   k_fast_compact  one thread per segment walks its set bits in x order -> raw_xy/raw_score
@@ -28,10 +30,15 @@ __global__ __launch_bounds__(256) void k_fast_planes(const float *__restrict__ g
                                                      unsigned long long *__restrict__ seg, int ntx)
 {
     __shared__ float tile[LROWS][LSTRIDE];
+    __shared__ uint16_t queue[TW * TH];  // pixels that passed the compass test: row << 10 | column << 4 | compass bits
+    __shared__ unsigned planes[TH][3][2]; // score bit planes of the tile, one 64-bit word per row and plane
+    __shared__ unsigned qcount;
     const int tx = blockIdx.x, ty = blockIdx.y, f = blockIdx.z;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float *g = gray + (size_t)f * W * H;
     const int x0 = tx * TW - HALO, y0 = ty * TH - HALO;
+    if (threadIdx.x < TH * 6) (&planes[0][0][0])[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) qcount = 0u;
 
     // each wave owns tile rows wv, wv+4, ...; all global loads are issued before the first LDS store
     // (a load -> store loop serialises six HBM round trips per workgroup)
@@ -59,60 +66,98 @@ __global__ __launch_bounds__(256) void k_fast_planes(const float *__restrict__ g
     }
     __syncthreads();
 
+    // Pass 1, every pixel: the four compass samples (:116-133).  A pixel goes on only with at most one of them
+    // similar (14 % of the pixels of a textured frame, but almost every 64-pixel row has one: testing the
+    // whole ring per wavefront row would run the long path at 14 % lane use).  Survivors are queued in LDS.
     const int x = tx * TW + lane;
+    const bool xin = x >= 3 && x < W - 3; // KeypointDetection.cs:45-47
 #pragma unroll 1
     for (int k = 0; k < TH / 4; k++) {
         const int ry = wv * (TH / 4) + k;
         const int y = ty * TH + ry;
         if (y >= H) break; // wave-uniform
-        int score = 0;
-        if (x >= 3 && x < W - 3 && y >= 3 && y < H - 3) { // KeypointDetection.cs:45-47
+        bool pass = false;
+        unsigned cb = 0;
+        if (xin && y >= 3 && y < H - 3) {
             const float c = tile[ry + 3][lane + 3];
             const float lo = __fsub_rn(c, T), hi = __fadd_rn(c, T); // :137, one rounding each
 #define PGX_SIM(dx, dy) ((tile[ry + 3 + (dy)][lane + 3 + (dx)] > lo) & (tile[ry + 3 + (dy)][lane + 3 + (dx)] < hi))
-            // cheap reject first: the four compass samples (:116-133)
             const unsigned s0 = PGX_SIM(-3, 0), s4 = PGX_SIM(0, 3), s8 = PGX_SIM(3, 0), s12 = PGX_SIM(0, -3);
-            if (s0 + s4 + s8 + s12 <= 1u) {
-                unsigned S = s0 | (s4 << 4) | (s8 << 8) | (s12 << 12);
-                const unsigned s1 = PGX_SIM(-3, 1);
-                S |= s1 << 1;
-                S |= (unsigned)PGX_SIM(-2, 2) << 2;
-                S |= (unsigned)PGX_SIM(-1, 3) << 3;
-                S |= (unsigned)PGX_SIM(1, 3) << 5;
-                S |= (unsigned)PGX_SIM(2, 2) << 6;
-                S |= (unsigned)PGX_SIM(3, 1) << 7;
-                S |= (unsigned)PGX_SIM(3, -1) << 9;
-                S |= (unsigned)PGX_SIM(2, -2) << 10;
-                S |= (unsigned)PGX_SIM(1, -3) << 11;
-                S |= (unsigned)PGX_SIM(-1, -3) << 13;
-                S |= (unsigned)PGX_SIM(-2, -2) << 14;
-                S |= s1 << 15; // entry 15 = (-3, 1) again (:18)
 #undef PGX_SIM
-                if (S == 0u) {
-                    score = 16;
-                } else {
-                    const unsigned D = ~S & 0xFFFFu;
-                    const unsigned dd = D | (D << 16);
-                    const unsigned x1 = dd & (dd >> 1);
-                    const unsigned x2 = x1 & (x1 >> 2);
-                    const unsigned x3 = x2 & (x2 >> 4);
-                    const unsigned t12 = x3 & (x2 >> 8);
-                    if (t12) {
-                        const unsigned t13 = t12 & (dd >> 12);
-                        const unsigned t14 = t13 & (dd >> 13);
-                        const unsigned t15 = t14 & (dd >> 14);
-                        score = 12 + (t13 != 0u) + (t14 != 0u) + (t15 != 0u);
-                    }
-                }
+            pass = s0 + s4 + s8 + s12 <= 1u;
+            cb = s0 | (s4 << 1) | (s8 << 2) | (s12 << 3);
+        }
+        const unsigned long long pm = __ballot(pass);
+        if (pm) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&qcount, (unsigned)__popcll(pm));
+            base = (unsigned)__shfl((int)base, 0);
+            if (pass) queue[base + (unsigned)__popcll(pm & ((1ull << lane) - 1ull))] = (uint16_t)((ry << 10) | (lane << 4) | cb);
+        }
+    }
+    __syncthreads();
+
+    // Pass 2, queued pixels only, all lanes busy: the other ring samples and the run-length rule; the
+    // score bits go into the tile's ballot planes with LDS atomics (order-independent, so deterministic).
+    const unsigned nq = qcount;
+    for (unsigned e = threadIdx.x; e < nq; e += 256) {
+        const unsigned q = queue[e];
+        const int ry = (int)(q >> 10), lx = (int)((q >> 4) & 63u);
+        const float c = tile[ry + 3][lx + 3];
+        const float lo = __fsub_rn(c, T), hi = __fadd_rn(c, T);
+#define PGX_SIM(dx, dy) ((unsigned)((tile[ry + 3 + (dy)][lx + 3 + (dx)] > lo) & (tile[ry + 3 + (dy)][lx + 3 + (dx)] < hi)))
+        unsigned S = (q & 1u) | ((q & 2u) << 3) | ((q & 4u) << 6) | ((q & 8u) << 9); // ring entries 0, 4, 8, 12
+        const unsigned s1 = PGX_SIM(-3, 1);
+        S |= s1 << 1;
+        S |= PGX_SIM(-2, 2) << 2;
+        S |= PGX_SIM(-1, 3) << 3;
+        S |= PGX_SIM(1, 3) << 5;
+        S |= PGX_SIM(2, 2) << 6;
+        S |= PGX_SIM(3, 1) << 7;
+        S |= PGX_SIM(3, -1) << 9;
+        S |= PGX_SIM(2, -2) << 10;
+        S |= PGX_SIM(1, -3) << 11;
+        S |= PGX_SIM(-1, -3) << 13;
+        S |= PGX_SIM(-2, -2) << 14;
+        S |= s1 << 15; // entry 15 = (-3, 1) again (:18)
+#undef PGX_SIM
+        int score = 0;
+        if (S == 0u) {
+            score = 16;
+        } else { // longest circular run of "different" samples, kept when >= 12 (:65-113)
+            const unsigned D = ~S & 0xFFFFu;
+            const unsigned dd = D | (D << 16);
+            const unsigned x1 = dd & (dd >> 1);
+            const unsigned x2 = x1 & (x1 >> 2);
+            const unsigned x3 = x2 & (x2 >> 4);
+            const unsigned t12 = x3 & (x2 >> 8);
+            if (t12) {
+                const unsigned t13 = t12 & (dd >> 12);
+                const unsigned t14 = t13 & (dd >> 13);
+                const unsigned t15 = t14 & (dd >> 14);
+                score = 12 + (t13 != 0u) + (t14 != 0u) + (t15 != 0u);
             }
         }
-        const int code = score ? score - 11 : 0; // 1..5
-        const unsigned long long b0 = __ballot(code & 1), b1 = __ballot(code & 2), b2 = __ballot(code & 4);
-        if (lane == 0) {
+        if (score) {
+            const int code = score - 11; // 1..5
+            const unsigned bit = 1u << (lx & 31);
+            unsigned *pw = &planes[ry][0][lx >> 5];
+            if (code & 1) atomicOr(pw, bit);
+            if (code & 2) atomicOr(pw + 2, bit);
+            if (code & 4) atomicOr(pw + 4, bit);
+        }
+    }
+    __syncthreads();
+
+    if (threadIdx.x < TH) {
+        const int ry = threadIdx.x, y = ty * TH + ry;
+        if (y < H) {
+            const unsigned long long b0 = planes[ry][0][0] | ((unsigned long long)planes[ry][0][1] << 32);
+            const unsigned long long b1 = planes[ry][1][0] | ((unsigned long long)planes[ry][1][1] << 32);
+            const unsigned long long b2 = planes[ry][2][0] | ((unsigned long long)planes[ry][2][1] << 32);
             unsigned long long *o = seg + (((size_t)f * H + y) * ntx + tx) * 4;
-            const unsigned long long any = b0 | b1 | b2;
             *reinterpret_cast<ulonglong2 *>(o) = make_ulonglong2(b0, b1);
-            *reinterpret_cast<ulonglong2 *>(o + 2) = make_ulonglong2(b2, (unsigned long long)__popcll(any));
+            *reinterpret_cast<ulonglong2 *>(o + 2) = make_ulonglong2(b2, (unsigned long long)__popcll(b0 | b1 | b2));
         }
     }
 }
