@@ -15,6 +15,8 @@ Extra objects on the JSON line:
                recorded on the launch stream during the timed steps)
   kernels      per-kernel-group launches / avg ms over the timed region
   match_only   pairs/s of the match stage alone (SURVEY 8d's definition of the metric)
+  overlap      the same K steps timed again with --overlap-streams contexts in flight (informative:
+               `value` is always the single-stream figure unless --streams says otherwise)
   cpu_baseline the CPU oracle (literal single-thread port of the C#) timed on a bounded sample
 """
 import argparse
@@ -104,6 +106,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dewarp", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="steps kept in flight (one pgx context + HIP stream each)")
+    ap.add_argument("--overlap-streams", type=int, default=2,
+                    help="after the timed region, time the same K steps again with this many contexts/streams in flight "
+                         "and report it as `overlap` (0 = skip); `value` always comes from --streams")
     args = ap.parse_args()
 
     import torch
@@ -127,11 +132,12 @@ def main():
     pairs = pg.make_brief_pairs(0, 50, P)
     dmap = None if args.no_dewarp else pg.build_dewarp_map(W, H, [3e-4, 1e-7, 0, 0, 0])
     NS = max(1, args.streams)
+    NO = max(0, args.overlap_streams)
     CAP = 8192
     d_frames = torch.from_numpy(frames_h).to(dev)
     pairlist = torch.tensor([[2 * p, 2 * p + 1] for p in range(B)], dtype=torch.int32, device=dev)
     engs, bufs = [], []
-    for _ in range(NS):
+    for _ in range(max(NS, NO)):
         e = pg.Engine(local_rank)          # own non-blocking HIP stream per context
         e.set_brief_pairs(pairs)
         e.set_detect_params(THRESH, RADIUS)
@@ -149,8 +155,8 @@ def main():
     log("[rank %d] setup %.1fs, %d frames resident (%.0f MB), %d stream(s)" % (rank, time.time() - t_setup, F, d_frames.numel() * 2 / 1e6, NS))
     step_no = [0]
 
-    def step():
-        k = step_no[0] % NS
+    def step(ns=NS):
+        k = step_no[0] % ns
         step_no[0] += 1
         e, b = engs[k], bufs[k]
         e.detect_batch_dev(d_frames, F, W, H, b["kp"], b["desc"], b["counts"], b["nraw"], CAP)
@@ -161,9 +167,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, NS)):
-        step()
+    for _ in range(max(args.warmup, NS, NO)):
+        step(max(NS, NO))
     torch.cuda.synchronize()
+    step_no[0] = 0
     # NMS survivors above the output capacity only flag a truncation here; anything else is fatal
     try:
         eng.check_status()
@@ -175,7 +182,7 @@ def main():
     pairs_per_step = int(sum(int(n_used[2 * p]) * int(n_used[2 * p + 1]) for p in range(B)))
     log("[rank %d] survivors per frame %s, raw %s" % (rank, counts.tolist(), nraw.tolist()))
 
-    for e in engs:
+    for e in engs[:NS]:
         e.profile_reset()
         e.profile_enable(True)
     barrier()
@@ -184,8 +191,20 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    for e in engs:
+    for e in engs[:NS]:
         e.profile_enable(False)
+
+    # the same K steps again with NO contexts in flight (events off): what stream-level overlap of the narrow
+    # kernels (scans, tails, the per-pair finish) is worth; reported beside `value`, never as `value`
+    dt_overlap = None
+    if NO > 1 and NO != NS:
+        step_no[0] = 0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(NO)
+        barrier()
+        dt_overlap = time.perf_counter() - t0
 
     # one exchange step: every rank's match lists -> all ranks (input of the track graph)
     if world > 1:
@@ -193,19 +212,20 @@ def main():
         dist.all_gather(gathered, d_out)
         torch.cuda.synchronize()
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, dt_overlap if dt_overlap is not None else 0.0], dtype=torch.float64, device=dev)
     tot_pairs = torch.tensor([pairs_per_step], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot_pairs, op=dist.ReduceOp.SUM)
-    dt_max = float(t.item())
+    dt_max = float(t[0].item())
+    dt_overlap_max = float(t[1].item())
     job_pairs_per_step = float(tot_pairs.item())
 
     if rank == 0:
         kern = {}
         for name in ("dewarp_gray", "fast", "nms", "brief", "match_init", "ham_argmin", "match_select", "tail_fill", "match_finish"):
             n, ms = 0, 0.0
-            for e in engs:
+            for e in engs[:NS]:
                 n_e, ms_e = e.profile_get(name)
                 n, ms = n + n_e, ms + ms_e
             if n:
@@ -227,8 +247,11 @@ def main():
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")   # HBM bytes per frame from separate rocprofv3 --pmc passes
         if os.path.exists(tpath):
-            for k, v in json.load(open(tpath)).get("bytes_per_frame", {}).items():
+            tj = json.load(open(tpath))
+            for k, v in tj.get("bytes_per_frame", {}).items():
                 traffic[k] = v * F
+            for k, v in tj.get("bytes_per_pair", {}).items():
+                traffic[k] = v * B
         rooflines = {}
         if "dewarp_gray" in kern:
             per_px = 12.0 if dmap is None else 20.0
@@ -249,7 +272,7 @@ def main():
             t = kern["ham_argmin"]["ms_per_step"] * 1e-3
             rooflines["ham_argmin"] = {"kernel": "ham_argmin", "bound": "mfma", "achieved": ops / t / 1e12,
                                        "peak": I8_MFMA_PEAK_OPS / 1e12, "unit": "TOP/s", "frac": ops / t / I8_MFMA_PEAK_OPS,
-                                       "traffic": None,
+                                       "traffic": traffic.get("ham_argmin"),
                                        "algorithmic": "2*P = 512 int8 ops per descriptor-pair evaluation x %d evaluations "
                                                       "per step over %d launches" % (evals, rounds_wide)}
         if detect_ms:
@@ -275,6 +298,10 @@ def main():
             "roofline": roof,
             "rooflines": rooflines,
             "kernels": kern,
+            "overlap": ({"streams": NO, "value": job_pairs_per_step * args.steps / dt_overlap_max,
+                         "ms_per_step": dt_overlap_max / args.steps * 1e3,
+                         "note": "same K steps with %d contexts/HIP streams in flight, events off" % NO}
+                        if dt_overlap_max > 0 else None),
             "detect": {"ms_per_step": detect_ms, "frames_per_s": F / (detect_ms * 1e-3) if detect_ms else None},
             "match_only": {"ms_per_step": match_ms,
                            "pairs_per_s": pairs_per_step / (match_ms * 1e-3) if match_ms else None,
