@@ -254,9 +254,11 @@ def main():
                 traffic[k] = v * B
         rooflines = {}
         if "dewarp_gray" in kern:
-            per_px = 12.0 if dmap is None else 20.0
+            # 8 B gathered source + 4 B grey per pixel and frame; the 8 B/px map is read once per group of 4 frames
+            # (k_image.hip FB = 4), i.e. 2 B/px/frame -- the minimum this kernel's blocking allows
+            per_px = 12.0 if dmap is None else 14.0
             rooflines["dewarp_gray"] = hbm("dewarp_gray", per_px * npix * F,
-                                           "%.0f B/pixel (8 map + 8 gathered source + 4 grey) x %d px x %d frames per launch" % (per_px, npix, F))
+                                           "%.0f B/pixel/frame (8 gathered source + 4 grey + 8 map per 4 frames) x %d px x %d frames per launch" % (per_px, npix, F))
         if "fast" in kern:
             rooflines["fast"] = hbm("fast", 4.5 * npix * F + 16.0 * n_raw_tot,
                                     "4 B/px grey read + 0.5 B/px ballot planes + 16 B per raw hit, %d frames (3 launches)" % F)

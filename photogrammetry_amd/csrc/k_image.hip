@@ -2,9 +2,10 @@
 //
 // Reference: ImageProcessing/DeWarp.cs:19-37 (integer gather through the Matrix<Uv> table) and
 // Images.Abstractions/Pixels/Grayscale.cs:19-23 (K = ((float)R + B + G) / (3*65535), float32).
-// HBM-bound: per pixel 8 B map + 8 B gathered source + 4 B grey (20 B; FAST re-reads the 4 B).
-// Layout: every thread owns 4 consecutive output pixels -> two 16-B map loads, four 8-B
-// gathers, one 16-B grey store; the map is shared by all frames of a batch (blockIdx.y).
+// HBM-bound: per pixel and frame 8 B gathered source + 4 B grey, plus 8 B of map per pixel and group of
+// FB = 4 frames (the map is the same for every frame of a batch): 14 B/px/frame; FAST re-reads the 4 B.
+// Layout: every thread owns 4 consecutive output pixels of FB frames -> two 16-B map loads, then per
+// frame four 8-B gathers and one 16-B grey store.
 #include "pgx_internal.h"
 
 namespace {
@@ -18,23 +19,24 @@ __device__ __forceinline__ float gray_of(uint2 px)
     return __fdiv_rn(s, 196605.0f);
 }
 
+constexpr int FB = 4; // frames per thread: one map read serves FB frames
+
 template <bool HAS_MAP, bool WRITE_RGBA>
 __global__ __launch_bounds__(256) void k_dewarp_gray(const uint2 *__restrict__ rgba, const int2 *__restrict__ map,
-                                                     int W, int H, float *__restrict__ gray,
+                                                     int W, int H, int F, float *__restrict__ gray,
                                                      uint2 *__restrict__ dewarped, int *status)
 {
     const size_t npix = (size_t)W * H;
-    const size_t f = blockIdx.y;
-    const uint2 *src = rgba + f * npix;
-    float *gout = gray ? gray + f * npix : nullptr;
-    uint2 *dout = WRITE_RGBA ? dewarped + f * npix : nullptr;
+    const int f0 = blockIdx.y * FB;
+    const int nf = F - f0 < FB ? F - f0 : FB; // block-uniform
     const size_t ngroups = (npix + 3) / 4;
     bool oob = false;
     for (size_t grp = (size_t)blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups;
          grp += (size_t)gridDim.x * blockDim.x) {
         const size_t i0 = grp * 4;
-        uint2 px[4];
         if (i0 + 3 < npix) {
+            size_t so[4]; // source offsets of the four output pixels, the same in every frame
+            bool ok[4];
             if (HAS_MAP) {
                 const int4 m01 = *reinterpret_cast<const int4 *>(map + i0);
                 const int4 m23 = *reinterpret_cast<const int4 *>(map + i0 + 2);
@@ -43,39 +45,60 @@ __global__ __launch_bounds__(256) void k_dewarp_gray(const uint2 *__restrict__ r
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     // (ushort) casts are unchecked in the C#: value mod 65536, then the bounds assert
-                    unsigned su = (unsigned)us[k] & 0xFFFFu, sv = (unsigned)vs[k] & 0xFFFFu;
-                    bool ok = su < (unsigned)W && sv < (unsigned)H;
-                    oob |= !ok;
-                    px[k] = ok ? src[(size_t)sv * W + su] : make_uint2(0, 0);
+                    const unsigned su = (unsigned)us[k] & 0xFFFFu, sv = (unsigned)vs[k] & 0xFFFFu;
+                    ok[k] = su < (unsigned)W && sv < (unsigned)H;
+                    oob |= !ok[k];
+                    so[k] = ok[k] ? (size_t)sv * W + su : 0;
                 }
-            } else {
-                const uint4 a = *reinterpret_cast<const uint4 *>(src + i0);
-                const uint4 b = *reinterpret_cast<const uint4 *>(src + i0 + 2);
-                px[0] = make_uint2(a.x, a.y); px[1] = make_uint2(a.z, a.w);
-                px[2] = make_uint2(b.x, b.y); px[3] = make_uint2(b.z, b.w);
             }
-            if (gout) {
-                float4 g4 = make_float4(gray_of(px[0]), gray_of(px[1]), gray_of(px[2]), gray_of(px[3]));
-                *reinterpret_cast<float4 *>(gout + i0) = g4;
+            uint2 px[FB][4];
+#pragma unroll
+            for (int fb = 0; fb < FB; fb++) {
+                if (fb >= nf) break;
+                const uint2 *src = rgba + (size_t)(f0 + fb) * npix;
+                if (HAS_MAP) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) px[fb][k] = src[so[k]];
+                } else {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(src + i0);
+                    const uint4 b = *reinterpret_cast<const uint4 *>(src + i0 + 2);
+                    px[fb][0] = make_uint2(a.x, a.y); px[fb][1] = make_uint2(a.z, a.w);
+                    px[fb][2] = make_uint2(b.x, b.y); px[fb][3] = make_uint2(b.z, b.w);
+                }
             }
-            if (WRITE_RGBA) {
-                *reinterpret_cast<uint4 *>(dout + i0) = make_uint4(px[0].x, px[0].y, px[1].x, px[1].y);
-                *reinterpret_cast<uint4 *>(dout + i0 + 2) = make_uint4(px[2].x, px[2].y, px[3].x, px[3].y);
+#pragma unroll
+            for (int fb = 0; fb < FB; fb++) {
+                if (fb >= nf) break;
+                if (HAS_MAP) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (!ok[k]) px[fb][k] = make_uint2(0, 0);
+                }
+                if (gray) {
+                    const float4 g4 = make_float4(gray_of(px[fb][0]), gray_of(px[fb][1]), gray_of(px[fb][2]), gray_of(px[fb][3]));
+                    *reinterpret_cast<float4 *>(gray + (size_t)(f0 + fb) * npix + i0) = g4;
+                }
+                if (WRITE_RGBA) {
+                    uint2 *dout = dewarped + (size_t)(f0 + fb) * npix;
+                    *reinterpret_cast<uint4 *>(dout + i0) = make_uint4(px[fb][0].x, px[fb][0].y, px[fb][1].x, px[fb][1].y);
+                    *reinterpret_cast<uint4 *>(dout + i0 + 2) = make_uint4(px[fb][2].x, px[fb][2].y, px[fb][3].x, px[fb][3].y);
+                }
             }
         } else {
             for (size_t i = i0; i < npix; i++) {
-                uint2 p;
+                size_t o = i;
+                bool okk = true;
                 if (HAS_MAP) {
-                    int2 m = map[i];
-                    unsigned su = (unsigned)m.x & 0xFFFFu, sv = (unsigned)m.y & 0xFFFFu;
-                    bool ok = su < (unsigned)W && sv < (unsigned)H;
-                    oob |= !ok;
-                    p = ok ? src[(size_t)sv * W + su] : make_uint2(0, 0);
-                } else {
-                    p = src[i];
+                    const int2 m = map[i];
+                    const unsigned su = (unsigned)m.x & 0xFFFFu, sv = (unsigned)m.y & 0xFFFFu;
+                    okk = su < (unsigned)W && sv < (unsigned)H;
+                    oob |= !okk;
+                    o = okk ? (size_t)sv * W + su : 0;
                 }
-                if (gout) gout[i] = gray_of(p);
-                if (WRITE_RGBA) dout[i] = p;
+                for (int fb = 0; fb < nf; fb++) {
+                    const uint2 p = okk ? rgba[(size_t)(f0 + fb) * npix + o] : make_uint2(0, 0);
+                    if (gray) gray[(size_t)(f0 + fb) * npix + i] = gray_of(p);
+                    if (WRITE_RGBA) dewarped[(size_t)(f0 + fb) * npix + i] = p;
+                }
             }
         }
     }
@@ -91,15 +114,15 @@ void pgx_launch_dewarp_gray(hipStream_t s, const uint16_t *rgba, const int32_t *
     const size_t ngroups = ((size_t)W * H + 3) / 4;
     unsigned gx = (unsigned)((ngroups + 255) / 256);
     if (gx > 4096u) gx = 4096u; // >> 256 CUs, grid-stride beyond
-    dim3 grid(gx, (unsigned)F), block(256);
+    dim3 grid(gx, (unsigned)((F + FB - 1) / FB)), block(256);
     const uint2 *src = reinterpret_cast<const uint2 *>(rgba);
     const int2 *map = reinterpret_cast<const int2 *>(map_uv);
     uint2 *dw = reinterpret_cast<uint2 *>(dewarped);
     if (map) {
-        if (dw) hipLaunchKernelGGL((k_dewarp_gray<true, true>), grid, block, 0, s, src, map, W, H, gray, dw, status);
-        else hipLaunchKernelGGL((k_dewarp_gray<true, false>), grid, block, 0, s, src, map, W, H, gray, dw, status);
+        if (dw) hipLaunchKernelGGL((k_dewarp_gray<true, true>), grid, block, 0, s, src, map, W, H, F, gray, dw, status);
+        else hipLaunchKernelGGL((k_dewarp_gray<true, false>), grid, block, 0, s, src, map, W, H, F, gray, dw, status);
     } else {
-        if (dw) hipLaunchKernelGGL((k_dewarp_gray<false, true>), grid, block, 0, s, src, map, W, H, gray, dw, status);
-        else hipLaunchKernelGGL((k_dewarp_gray<false, false>), grid, block, 0, s, src, map, W, H, gray, dw, status);
+        if (dw) hipLaunchKernelGGL((k_dewarp_gray<false, true>), grid, block, 0, s, src, map, W, H, F, gray, dw, status);
+        else hipLaunchKernelGGL((k_dewarp_gray<false, false>), grid, block, 0, s, src, map, W, H, F, gray, dw, status);
     }
 }
