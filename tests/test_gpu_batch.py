@@ -157,3 +157,41 @@ def test_profile_hooks_and_stats(engine):
     assert rounds >= 1 and ev0 == 2000 * 2000 and evals >= ev0
     engine.profile_reset()
     assert engine.profile_get("ham_argmin") == (0, 0.0)
+
+
+@pytest.mark.parametrize("radius", [16, 20, 25, 45, 100])
+def test_detect_full_size_frames_vs_oracle(engine, radius):
+    """The bench workload's frame shape: 1920x1080, ~1e5 raw hits per frame, dewarp map on, two frames per launch
+    (one of them a shifted copy), every stage compared bit-exactly with the oracle.  The radii cover every cell
+    size / reach combination of the NMS champion rounds (8 px: reach 2 and 3; 16 px; 32 px; 64 px)."""
+    W, H, CAP, RAW = 1920, 1080, 16384, 1 << 18
+    T = np.float32(0.1)
+    base = synth.make_frame(W, H, seed=11, n_shapes=12000)
+    frames = np.stack([base, synth.shift_frame(base, 37, 11)])
+    pairs = pg.make_brief_pairs(0, 50, 256)
+    dmap = pg.build_dewarp_map(W, H, [3e-4, 1e-7, 0, 0, 0])
+    engine.set_brief_pairs(pairs)
+    engine.set_detect_params(T, radius)
+    engine.set_capacity(RAW, CAP)
+    engine.set_dewarp_map(dmap)
+    F = 2
+    d_frames = torch.from_numpy(frames).to(DEV)
+    d_kp = torch.zeros((F, CAP, 4), dtype=torch.int32, device=DEV)
+    d_desc = torch.zeros((F, CAP, 8), dtype=torch.int32, device=DEV)
+    d_counts = torch.zeros(F, dtype=torch.int32, device=DEV)
+    d_nraw = torch.zeros(F, dtype=torch.int32, device=DEV)
+    engine.detect_batch_dev(d_frames, F, W, H, d_kp, d_desc, d_counts, d_nraw, CAP)
+    engine.check_status()
+    kp = d_kp.cpu().numpy()
+    desc = d_desc.cpu().numpy().view(np.uint32)
+    counts, nraw = d_counts.cpu().numpy(), d_nraw.cpu().numpy()
+    for f in range(F):
+        kept, edesc, n_raw = _oracle_detect(frames[f], dmap, pairs, T, radius, CAP)
+        assert n_raw > 30000 and nraw[f] == n_raw
+        assert counts[f] == len(kept), (f, counts[f], len(kept))
+        n = len(kept)
+        assert (kp[f, :n, 0] == kept["x"]).all() and (kp[f, :n, 1] == kept["y"]).all()
+        assert (kp[f, :n, 2] == kept["fast_score"]).all()
+        assert kp[f, :n, 3].view(np.float32).tobytes() == kept["value"].tobytes()
+        assert (desc[f, :n] == edesc).all()
+    engine.set_dewarp_map(None)
