@@ -449,45 +449,61 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
     // min over the alive entries of cached rows, 8 distances per 16-B load; a wavefront takes
     // four dirty rows at a time and issues all their loads before using any (the scan is bound
     // by L2 latency, not bandwidth)
-    auto scan_rows4 = [&](const uint16_t *mat, int stride, int n, const uint8_t *alive, const uint32_t *list,
-                          int nlist, uint32_t *bestout) {
-        for (int k0 = wv * 4; k0 < nlist; k0 += nw * 4) {
-            int idx[4];
-            uint32_t best[4];
+    // Dirty rows (scanned in D against the alive columns) and dirty columns (in DT against the alive rows) go
+    // through TOGETHER: a wavefront takes four of each and issues all sixteen 16-B loads before using any,
+    // so a round costs one L2 round trip, not one per side.
+    constexpr int NE = 3; // rows and columns per wavefront and pass (register budget: 128 at 1024 threads)
+    auto scan_dirty = [&](int nrd, int ncd) {
+        const int nmax = nrd > ncd ? nrd : ncd;
+        for (int k0 = wv * NE; k0 < nmax; k0 += nw * NE) {
+            int ir[NE], ic[NE];
+            uint32_t br[NE], bc[NE];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { idx[u] = (k0 + u < nlist) ? (int)list[k0 + u] : -1; best[u] = PGX_KEY_NONE; }
-            for (int q0 = 0; q0 < n; q0 += 1024) { // two 512-entry chunks (8 loads) in flight per pass
-                uint4 v[4][2];
-                uint2 al[2];
+            for (int u = 0; u < NE; u++) {
+                ir[u] = (k0 + u < nrd) ? (int)rdl[k0 + u] : -1;
+                ic[u] = (k0 + u < ncd) ? (int)cdl[k0 + u] : -1;
+                br[u] = PGX_KEY_NONE; bc[u] = PGX_KEY_NONE;
+            }
+            const int nspan = C > R ? C : R;
+            for (int q0 = 0; q0 < nspan; q0 += 1024) { // two 512-entry chunks per side in flight
+                uint4 vr[NE][2], vc[NE][2];
+                uint2 alr[2], alc[2];
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const int j8 = q0 + lane * 8 + q * 512;
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        v[u][q] = (idx[u] >= 0 && j8 < n) ? *reinterpret_cast<const uint4 *>(mat + (size_t)idx[u] * stride + j8)
-                                                          : make_uint4(~0u, ~0u, ~0u, ~0u);
-                    al[q] = (j8 < n) ? *reinterpret_cast<const uint2 *>(alive + j8) : make_uint2(0, 0);
+                    for (int u = 0; u < NE; u++) {
+                        vr[u][q] = (ir[u] >= 0 && j8 < C) ? *reinterpret_cast<const uint4 *>(D + (size_t)ir[u] * Cs + j8) : make_uint4(~0u, ~0u, ~0u, ~0u);
+                        vc[u][q] = (ic[u] >= 0 && j8 < R) ? *reinterpret_cast<const uint4 *>(DT + (size_t)ic[u] * Rs + j8) : make_uint4(~0u, ~0u, ~0u, ~0u);
+                    }
+                    alr[q] = (j8 < C) ? *reinterpret_cast<const uint2 *>(calive + j8) : make_uint2(0, 0);
+                    alc[q] = (j8 < R) ? *reinterpret_cast<const uint2 *>(ralive + j8) : make_uint2(0, 0);
                 }
+                auto reduce = [&](const uint4 (&v)[NE][2], const uint2 (&al)[2], uint32_t (&best)[NE]) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < NE; u++) {
 #pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const int j8 = q0 + lane * 8 + q * 512;
-                        const uint32_t dw[4] = {v[u][q].x, v[u][q].y, v[u][q].z, v[u][q].w};
+                        for (int q = 0; q < 2; q++) {
+                            const int j8 = q0 + lane * 8 + q * 512;
+                            const uint32_t dw[4] = {v[u][q].x, v[u][q].y, v[u][q].z, v[u][q].w};
 #pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            const uint32_t d = (dw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-                            const uint32_t a = ((k < 4 ? al[q].x : al[q].y) >> (8 * (k & 3))) & 0xFFu;
-                            const uint32_t key = a ? ((d << PGX_IDX_BITS) | (uint32_t)(j8 + k)) : PGX_KEY_NONE;
-                            best[u] = key < best[u] ? key : best[u];
+                            for (int k = 0; k < 8; k++) {
+                                const uint32_t d = (dw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                                const uint32_t a = ((k < 4 ? al[q].x : al[q].y) >> (8 * (k & 3))) & 0xFFu;
+                                const uint32_t key = a ? ((d << PGX_IDX_BITS) | (uint32_t)(j8 + k)) : PGX_KEY_NONE;
+                                best[u] = key < best[u] ? key : best[u];
+                            }
                         }
                     }
-                }
+                };
+                reduce(vr, alr, br);
+                reduce(vc, alc, bc);
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t bst = wave_min_u32(best[u]);
-                if (lane == 0 && idx[u] >= 0) bestout[idx[u]] = bst;
+            for (int u = 0; u < NE; u++) {
+                const uint32_t b1 = wave_min_u32(br[u]), b2 = wave_min_u32(bc[u]);
+                if (lane == 0 && ir[u] >= 0) rbest[ir[u]] = b1;
+                if (lane == 0 && ic[u] >= 0) cbest[ic[u]] = b2;
             }
         }
     };
@@ -495,8 +511,7 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
     while (true) {
         const int nrd = (int)ctr[0], ncd = (int)ctr[1];
         if (tid == 0) { atomicAdd(&dbg[3], 1); atomicAdd(&dbg[4], nrd); atomicAdd(&dbg[5], ncd); }
-        scan_rows4(D, Cs, C, calive, rdl, nrd, rbest);
-        scan_rows4(DT, Rs, R, ralive, cdl, ncd, cbest);
+        scan_dirty(nrd, ncd);
         __syncthreads();
         if (tid == 0) { ctr[0] = 0; ctr[1] = 0; ctr[3] = 0; ctr[4] = 0; }
         // accept mutual edges (every alive row points at an alive column here)
