@@ -20,8 +20,10 @@
 //                 then the rest) and a ballot decides "beaten"; survivors are accepted and queued;
 //        phase B: one wavefront per NEWLY accepted point (a few thousand per frame in total): lanes =
 //                 its neighbours, every undecided one within r is suppressed; emits the sort key;
-//   k_nms_tail   one 1024-thread workgroup per frame: finishes whatever is still undecided, then
-//        sorts the accepted points (bitonic, LDS) and writes the order.
+//   k_nms_tail   one 1024-thread workgroup per frame: finishes whatever is still undecided (champion path: the
+//        same champion rounds on a compact list of the open cells, a block barrier instead of a kernel
+//        boundary -- long dependency chains need dozens of nearly empty rounds), then orders the accepted
+//        points (champion path: per-score-level rank bitmaps; otherwise a bitonic sort in LDS).
 // Integer work on L2-resident data (a few MB per frame); latency/issue-bound, not HBM-bound.
 #include "pgx_internal.h"
 #include <cstdlib>
@@ -29,7 +31,7 @@
 namespace {
 
 constexpr int NT = 1024;
-constexpr int WIDE_ROUNDS = 10;
+constexpr int WIDE_ROUNDS = 8; // champion path: 3..10 measure the same on 128 1080p frames (r = 16); 8..10 are best on 4K frames at r = 30
 constexpr uint32_t SORT_LDS_MAX = 16384; // u64 keys -> 128 KiB
 
 struct NmsLayout {
@@ -481,12 +483,8 @@ __global__ __launch_bounds__(256) void k_nms_phase_a(NmsLayout L, int radius, in
 //                 q's cell better still); only "better champion, but farther than r" needs the exact test
 //                 over the block's records, done by the whole wavefront for one such cell at a time.
 // The accepted set of a round is exactly the locally-best set of the plain formulation above.
-__global__ __launch_bounds__(256) void k_nms_champ(NmsLayout L, unsigned char *ws_all, size_t ws_stride)
+__device__ __forceinline__ void champ_cell(const NmsPtrs &P, const NmsLayout &L, int c)
 {
-    const int f = blockIdx.y;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= L.ncell) return;
-    NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
     if (P.cell_und[c] == 0) return; // its grid entry is already {0,0}
     uint32_t h = P.cell_fill[c];
     const uint32_t e = P.cell_start[c + 1];
@@ -514,14 +512,21 @@ __global__ __launch_bounds__(256) void k_nms_champ(NmsLayout L, unsigned char *w
     }
 }
 
-template <int RR>
-__global__ __launch_bounds__(256) void k_nms_phase_c(NmsLayout L, int radius, int round, unsigned char *ws_all,
-                                                     size_t ws_stride)
+
+__global__ __launch_bounds__(256) void k_nms_champ(NmsLayout L, unsigned char *ws_all, size_t ws_stride)
 {
-    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int f = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
-    NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
-    const bool incell = c < L.ncell;
+    if (c >= L.ncell) return;
+    const NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
+    champ_cell(P, L, c);
+}
+
+// called by whole wavefronts: lane = one cell (c, valid when incell)
+template <int RR>
+__device__ __forceinline__ void phase_c_wave(const NmsPtrs &P, const NmsLayout &L, int radius, int round, int c, bool incell)
+{
+    const int lane = threadIdx.x & 63;
     const int cc = incell ? c : 0;
     const int cy = cc / L.gw, cx = cc - cy * L.gw;
     const uint2 *crow = P.champ + (size_t)(cy + RR) * L.cgw + cx + RR;
@@ -610,6 +615,16 @@ __global__ __launch_bounds__(256) void k_nms_phase_c(NmsLayout L, int radius, in
     }
 }
 
+template <int RR>
+__global__ __launch_bounds__(256) void k_nms_phase_c(NmsLayout L, int radius, int round, unsigned char *ws_all,
+                                                     size_t ws_stride)
+{
+    const int f = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
+    phase_c_wave<RR>(P, L, radius, round, c, c < L.ncell);
+}
+
 // Phase B, one wavefront per NEWLY accepted point (a few thousand per frame over all rounds): retire
 // it to ACCEPTED, emit its sort key, and suppress every undecided point within r (lanes = neighbours).
 __global__ __launch_bounds__(256) void k_nms_push(NmsLayout L, int radius, int round, unsigned char *ws_all,
@@ -695,7 +710,7 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
                                                  const int32_t *__restrict__ n_raw_all, int n_cap, NmsLayout L,
                                                  int radius, unsigned char *ws_all, size_t ws_stride,
                                                  uint32_t *__restrict__ order_all, int32_t *__restrict__ n_kept_all,
-                                                 int kp_cap, int *status)
+                                                 int kp_cap, int *status, int round0)
 {
     extern __shared__ unsigned long long lds_keys[];
     __shared__ uint32_t wsum[NT / 64];
@@ -712,7 +727,47 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
     }
     const long long r2 = (long long)radius * (long long)radius;
 
-    if (radius >= 0) {
+    if (radius >= 0 && L.champ) {
+        // ---- champion rounds continued by this one workgroup on a compact list of the cells that are still
+        //      open: same two steps as the wide rounds (champ_cell, phase_c_wave), a block barrier in place of
+        //      the kernel boundary (all waves of a workgroup share one L1, so global writes made before the
+        //      barrier are seen after it).  Long dependency chains (large r, dense hits) need dozens of rounds
+        //      with little work each; here a round costs a few microseconds instead of two launches. ----
+        if (tid == 0) sh_cnt = 0;
+        __syncthreads();
+        for (int c = tid; c < L.ncell; c += NT)
+            if (P.cell_und[c] != 0) P.listA[atomicAdd(&sh_cnt, 1u)] = (uint32_t)c;
+        __syncthreads();
+        uint32_t *cur = P.listA, *nxt = P.listB;
+        int n_live = (int)sh_cnt;
+        int round = round0;
+        __syncthreads();
+        while (n_live > 0) {
+            for (int i = tid; i < n_live; i += NT) champ_cell(P, L, (int)cur[i]);
+            if (tid == 0) sh_cnt = 0;
+            __syncthreads();
+            for (int i = tid; i < n_live; i += NT) {
+                const uint32_t c = cur[i];
+                if (P.cell_und[c] != 0) nxt[atomicAdd(&sh_cnt, 1u)] = c; // order inside the list is irrelevant
+            }
+            __syncthreads();
+            n_live = (int)sh_cnt;
+            { uint32_t *t = cur; cur = nxt; nxt = t; }
+            for (int base = 0; base < n_live; base += NT) { // whole wavefronts: lane = one open cell
+                const int i = base + tid;
+                const bool in = i < n_live;
+                const int c = in ? (int)cur[i] : 0;
+                if (L.R <= 2) phase_c_wave<2>(P, L, radius, round, c, in);
+                else phase_c_wave<3>(P, L, radius, round, c, in);
+            }
+            __syncthreads();
+            round++;
+            if (round - round0 > (1 << 22)) { // every round closes at least the best open cell; anything else is a bug
+                if (tid == 0) atomicOr(status, (int)PGX_ST_INTERNAL);
+                break;
+            }
+        }
+    } else if (radius >= 0) {
         // ---- remaining rounds on an active list (normally empty after the wide rounds) ----
         if (tid == 0) sh_cnt = 0;
         __syncthreads();
@@ -881,6 +936,7 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
     const bool have_planes = seg && segoff;
     const NmsLayout L = nms_layout(W, H, radius, n_cap, have_planes);
     const bool rounds = radius >= 0;
+    int wide_rounds_used = 0;
     const dim3 pgrid((n_cap + 255) / 256, F);
     const dim3 cgrid((L.ncell + 3) / 4, F);
     if (rounds) {
@@ -895,6 +951,7 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
         else if (planes) hipLaunchKernelGGL(k_nms_bin_planes<1>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
         else hipLaunchKernelGGL(k_nms_scatter, pgrid, dim3(256), 0, s, raw_xy, raw_score, n_raw, n_cap, L, ws, ws_stride);
         static const int wide_rounds = [] { const char *e = getenv("PGX_NMS_ROUNDS"); int v = e ? atoi(e) : WIDE_ROUNDS; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+        wide_rounds_used = wide_rounds;
         for (int r = 0; r < wide_rounds; r++) {
             if (L.champ) {
                 if (r > 0) hipLaunchKernelGGL(k_nms_champ, bgrid, dim3(256), 0, s, L, ws, ws_stride);
@@ -913,5 +970,5 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
         attr_set = true;
     }
     hipLaunchKernelGGL(k_nms_tail, dim3(F), dim3(NT), SORT_LDS_MAX * 8, s, raw_score, n_raw, n_cap, L, radius, ws,
-                       ws_stride, order, n_kept, kp_cap, status);
+                       ws_stride, order, n_kept, kp_cap, status, rounds ? wide_rounds_used : 0);
 }
