@@ -10,7 +10,9 @@
 // one is suppressed (phase B).  Output = accepted points in priority order.  On a 1080p frame with
 // 1e5 raw hits the undecided set shrinks ~2.6x per round (9 rounds).
 //
-// Launch structure (all frames of a batch in every launch, blockIdx.y = frame):
+// Two launch structures (all frames of a batch in every launch, blockIdx.y = frame).  The fused detect path
+// with 10 <= r <= 192 uses the CHAMPION ROUNDS described further down (k_nms_bin_planes, k_nms_champ,
+// k_nms_phase_c); everything else (stage API, other radii) uses the general one:
 //   k_nms_zero / k_nms_count / k_nms_cellscan / k_nms_scatter   counting sort of the points into a
 //        uniform grid of cells >= r; each point becomes one 16-byte record {xy, score, index, state}
 //        in cell order, so a 3x3-cell neighbourhood is three contiguous runs of records;

@@ -195,3 +195,31 @@ def test_detect_full_size_frames_vs_oracle(engine, radius):
         assert kp[f, :n, 3].view(np.float32).tobytes() == kept["value"].tobytes()
         assert (desc[f, :n] == edesc).all()
     engine.set_dewarp_map(None)
+
+
+def test_detect_4k_frame_vs_oracle(engine):
+    """SURVEY 8d config 4's frame shape: 3840x2160, r = 22 (16-px cells), > 8192 survivors, ~3e5 raw hits."""
+    W, H, CAP, RAW, radius = 3840, 2160, 16384, 1 << 20, 22
+    T = np.float32(0.1)
+    frame = synth.make_frame(W, H, seed=5, n_shapes=80000)
+    pairs = pg.make_brief_pairs(0, 50, 256)
+    dmap = pg.build_dewarp_map(W, H, [3e-4, 1e-7, 0, 0, 0])
+    engine.set_brief_pairs(pairs)
+    engine.set_detect_params(T, radius)
+    engine.set_capacity(RAW, CAP)
+    engine.set_dewarp_map(dmap)
+    d_frames = torch.from_numpy(frame[None]).to(DEV)
+    d_kp = torch.zeros((1, CAP, 4), dtype=torch.int32, device=DEV)
+    d_desc = torch.zeros((1, CAP, 8), dtype=torch.int32, device=DEV)
+    d_counts = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d_nraw = torch.zeros(1, dtype=torch.int32, device=DEV)
+    engine.detect_batch_dev(d_frames, 1, W, H, d_kp, d_desc, d_counts, d_nraw, CAP)
+    engine.check_status()
+    kept, edesc, n_raw = _oracle_detect(frame, dmap, pairs, T, radius, CAP)
+    n = len(kept)
+    assert n > 8192 and int(d_nraw[0]) == n_raw and int(d_counts[0]) == n
+    kp = d_kp.cpu().numpy()[0]
+    assert (kp[:n, 0] == kept["x"]).all() and (kp[:n, 1] == kept["y"]).all() and (kp[:n, 2] == kept["fast_score"]).all()
+    assert kp[:n, 3].view(np.float32).tobytes() == kept["value"].tobytes()
+    assert (d_desc.cpu().numpy().view(np.uint32)[0, :n] == edesc).all()
+    engine.set_dewarp_map(None)
