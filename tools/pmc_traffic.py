@@ -5,9 +5,9 @@ Collect (on the GPU box, separate passes, counters only with --kernel-trace, as 
 
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_f -o f --output-format csv -- \
-      python3 bench.py --steps 3 --warmup 1 --pairs-per-step 8 --cpu-sample 0
+      python3 bench.py --steps 3 --warmup 1 --pairs-per-step 8 --cpu-sample 0 --overlap-streams 0
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_w -o w --output-format csv -- \
-      python3 bench.py --steps 3 --warmup 1 --pairs-per-step 8 --cpu-sample 0
+      python3 bench.py --steps 3 --warmup 1 --pairs-per-step 8 --cpu-sample 0 --overlap-streams 0
 
 then:  python tools/pmc_traffic.py gpurun_out/pmc_f/f_counter_collection.csv \
                                    gpurun_out/pmc_w/w_counter_collection.csv 16 profiles/r01_traffic.json
@@ -75,7 +75,7 @@ def main():
     detect = ("dewarp_gray", "fast", "nms", "brief")
     res = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace) on "
-                  "`bench.py --steps 3 --warmup 1 --pairs-per-step %d --cpu-sample 0` (%d frames per launch), MI355X; "
+                  "`bench.py --steps 3 --warmup 1 --pairs-per-step %d --cpu-sample 0 --overlap-streams 0` (%d frames per launch), MI355X; "
                   "made by tools/pmc_traffic.py" % (frames // 2, frames),
         "units": "FETCH_SIZE/WRITE_SIZE are KB per dispatch; bytes = value*1024",
         "correction": "MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) "
