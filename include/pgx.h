@@ -67,6 +67,13 @@ int  pgx_check_status(pgx_ctx *ctx);
 /* DeWarpTransformStepFactory.Initialize (DeWarpTransformStepFactory.cs:26-31): the Matrix<Uv>
  * built by DeWarp.GetDistortionMatrix, as host int32 [H][W][2] = (U, V).  NULL = stage off. */
 int pgx_set_dewarp_map(pgx_ctx *ctx, const int32_t *uv, int W, int H);
+/* The same table built ON THE DEVICE from DeWarpOptions.DistortionCoefficients (DeWarp.GetDistortionMatrix,
+ * DeWarp.cs:39-107; exactly 5 coefficients or PGX_E_BADARG like DeWarp.cs:46-48): no 8-66 MB upload, no host
+ * loop.  Same float64 formulas as pgx_build_dewarp_map; the device's libm differs from the host's in the last
+ * ulp, so isolated entries can differ by +-1 from the host-built table ("within +-1 px, unpinned"). */
+int pgx_set_dewarp_coeffs(pgx_ctx *ctx, int W, int H, const double *coeffs, int ncoeffs);
+/* Copy the context's current table back to the host, int32 [H][W][2] (inspection / caching by the host). */
+int pgx_get_dewarp_map(pgx_ctx *ctx, int32_t *uv_out, int W, int H);
 /* KeypointDetection ctor's _gaussianKeypairs (KeypointDetection.cs:35-39): host int32 [P][4] =
  * (x1, y1, x2, y2).  The table is an INPUT because the reference draws it unseeded. */
 int pgx_set_brief_pairs(pgx_ctx *ctx, const int32_t *pairs, int P);

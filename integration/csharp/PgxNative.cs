@@ -23,6 +23,8 @@ internal static unsafe class PgxNative
     [DllImport(Lib)] public static extern void pgx_ctx_destroy(IntPtr ctx);
     [DllImport(Lib)] public static extern IntPtr pgx_last_error(IntPtr ctx);
     [DllImport(Lib)] public static extern int pgx_set_dewarp_map(IntPtr ctx, int* uv, int w, int h);
+    [DllImport(Lib)] public static extern int pgx_set_dewarp_coeffs(IntPtr ctx, int w, int h, double* coeffs, int ncoeffs);
+    [DllImport(Lib)] public static extern int pgx_get_dewarp_map(IntPtr ctx, int* uvOut, int w, int h);
     [DllImport(Lib)] public static extern int pgx_set_brief_pairs(IntPtr ctx, int* pairs, int p);
     [DllImport(Lib)] public static extern int pgx_set_detect_params(IntPtr ctx, float threshold, int suppressionRadius);
     [DllImport(Lib)] public static extern int pgx_set_capacity(IntPtr ctx, int maxRaw, int maxKeypoints);

@@ -19,7 +19,8 @@ PGX_DIST_NONE = 2**31 - 1
 # every symbol include/pgx.h declares (tests/test_abi_symbols.py checks the header against this)
 EXPORTS = [
     "pgx_ctx_create", "pgx_ctx_destroy", "pgx_last_error", "pgx_version", "pgx_set_stream",
-    "pgx_check_status", "pgx_set_dewarp_map", "pgx_set_brief_pairs", "pgx_set_detect_params",
+    "pgx_check_status", "pgx_set_dewarp_map", "pgx_set_dewarp_coeffs", "pgx_get_dewarp_map", "pgx_set_brief_pairs",
+    "pgx_set_detect_params",
     "pgx_set_capacity", "pgx_dewarp", "pgx_gray", "pgx_fast", "pgx_brief", "pgx_nms", "pgx_match",
     "pgx_detect", "pgx_detect_batch_dev", "pgx_match_batch_dev", "pgx_profile_enable",
     "pgx_profile_get", "pgx_profile_reset", "pgx_match_stats", "pgx_debug_counters", "pgx_make_brief_pairs",

@@ -102,6 +102,16 @@ class Engine:
         assert m.ndim == 3 and m.shape[2] == 2
         self._chk(self._L.pgx_set_dewarp_map(self._h, _ptr(m), m.shape[1], m.shape[0]))
 
+    def set_dewarp_coeffs(self, W, H, coeffs):
+        """Build the table on the device from the five distortion coefficients (DeWarp.GetDistortionMatrix)."""
+        k = np.ascontiguousarray(coeffs, dtype=np.float64).reshape(-1)
+        self._chk(self._L.pgx_set_dewarp_coeffs(self._h, int(W), int(H), _ptr(k), int(k.size)))
+
+    def get_dewarp_map(self, W, H):
+        out = np.zeros((H, W, 2), dtype=np.int32)
+        self._chk(self._L.pgx_get_dewarp_map(self._h, _ptr(out), int(W), int(H)))
+        return out
+
     def set_brief_pairs(self, pairs):
         p = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 4)
         self._chk(self._L.pgx_set_brief_pairs(self._h, _ptr(p), p.shape[0]))

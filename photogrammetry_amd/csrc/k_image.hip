@@ -105,6 +105,76 @@ __global__ __launch_bounds__(256) void k_dewarp_gray(const uint2 *__restrict__ r
     if (HAS_MAP && oob) atomicOr(status, (int)PGX_ST_OOB_SOURCE);
 }
 
+// ---- DeWarp.GetDistortionMatrix on the device ------------------------------------------
+// Reference: ImageProcessing/DeWarp.cs:39-107, same float64 formulas as the host builder
+// (pgx_hostutil.cpp): x = (int)(u - W/2.0), rd = sqrt(x^2+y^2), cubic r^3 + b r^2 + c r + d with
+// MathNet's Cubic.RealRoots restated, middle root of three else the smallest, theta = atan2(y, x),
+// (U, V) = ((int)(root cos theta + W/2.0), (int)(root sin theta + H/2.0)).  One thread per pixel; the
+// reference caches the root per r^2, which changes nothing in the values.  The device's libm (pow, acos,
+// cos, sin, atan2) is not bit-identical to the host's, so a truncation can land on the other side of an
+// integer: parity with the host table is "equal, except +-1 at isolated pixels" (tested), unpinned
+// against the reference like the host builder itself.
+__device__ __forceinline__ int32_t trunc_to_int_dev(double v)
+{
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return INT32_MIN;
+    return (int32_t)v;
+}
+
+__device__ __forceinline__ double cbrt_signed_dev(double n)
+{
+    const double sgn = (double)((n > 0) - (n < 0));
+    return pow(fabs(n), 1.0 / 3.0) * sgn;
+}
+
+__global__ __launch_bounds__(256) void k_dewarp_map(int W, int H, double k0, double k1, double k2, double k3, double k4,
+                                                    int2 *__restrict__ map, int *status)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)W * H) return;
+    const int v = (int)(i / W), u = (int)(i - (size_t)v * W);
+    const double x0 = W / 2.0, y0 = H / 2.0;
+    const int x = trunc_to_int_dev(u - x0), y = trunc_to_int_dev(v - y0);
+    const int rd2 = x * x + y * y;
+    const double rd = sqrt((double)rd2);
+    const double den = rd * k4 - k1;
+    const double a2 = (rd * k3 - k0) / den, a1 = (rd * k2 - 1) / den, a0 = rd / den;
+    const double Q = (3 * a1 - a2 * a2) / 9.0;
+    const double R = (9.0 * a2 * a1 - 27 * a0 - 2 * a2 * a2 * a2) / 54.0;
+    const double Q3 = Q * Q * Q;
+    const double D = Q3 + R * R;
+    const double shift = -a2 / 3.0;
+    const double nan = __longlong_as_double(0x7FF8000000000000ll);
+    double r0 = nan, r1 = nan, r2 = nan;
+    if (D >= 0) {
+        const double sqrtD = pow(D, 0.5);
+        const double S = cbrt_signed_dev(R + sqrtD), T = cbrt_signed_dev(R - sqrtD);
+        r0 = shift + (S + T);
+        if (D == 0) r1 = shift - S;
+    } else {
+        const double pi = 3.1415926535897932384626433832795;
+        const double theta = acos(R / sqrt(-Q3));
+        const double m = 2.0 * sqrt(-Q);
+        r0 = m * cos(theta / 3.0) + shift;
+        r1 = m * cos((theta + 2.0 * pi) / 3.0) + shift;
+        r2 = m * cos((theta - 2.0 * pi) / 3.0) + shift;
+    }
+    // drop NaN, sort ascending, middle of three else the smallest (DeWarp.cs:78-82)
+    double kept[3];
+    int n = 0;
+    if (!isnan(r0)) kept[n++] = r0;
+    if (!isnan(r1)) kept[n++] = r1;
+    if (!isnan(r2)) kept[n++] = r2;
+    if (n == 0) { atomicOr(status, (int)PGX_ST_INTERNAL); map[i] = make_int2(INT32_MIN, INT32_MIN); return; }
+    if (n >= 2 && kept[0] > kept[1]) { const double t = kept[0]; kept[0] = kept[1]; kept[1] = t; }
+    if (n == 3) {
+        if (kept[1] > kept[2]) { const double t = kept[1]; kept[1] = kept[2]; kept[2] = t; }
+        if (kept[0] > kept[1]) { const double t = kept[0]; kept[0] = kept[1]; kept[1] = t; }
+    }
+    const double root = n == 3 ? kept[1] : kept[0];
+    const double theta = atan2((double)y, (double)x);
+    map[i] = make_int2(trunc_to_int_dev(root * cos(theta) + x0), trunc_to_int_dev(root * sin(theta) + y0));
+}
+
 } // namespace
 
 void pgx_launch_dewarp_gray(hipStream_t s, const uint16_t *rgba, const int32_t *map_uv, int F, int W, int H,
@@ -125,4 +195,11 @@ void pgx_launch_dewarp_gray(hipStream_t s, const uint16_t *rgba, const int32_t *
         if (dw) hipLaunchKernelGGL((k_dewarp_gray<false, true>), grid, block, 0, s, src, map, W, H, F, gray, dw, status);
         else hipLaunchKernelGGL((k_dewarp_gray<false, false>), grid, block, 0, s, src, map, W, H, F, gray, dw, status);
     }
+}
+
+void pgx_launch_dewarp_map(hipStream_t s, int W, int H, const double *k, int32_t *map_uv, int *status)
+{
+    const size_t npix = (size_t)W * H;
+    hipLaunchKernelGGL(k_dewarp_map, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, W, H, k[0], k[1], k[2], k[3], k[4],
+                       reinterpret_cast<int2 *>(map_uv), status);
 }

@@ -220,6 +220,32 @@ int pgx_set_dewarp_map(pgx_ctx *c, const int32_t *uv, int W, int H)
     return PGX_OK;
 }
 
+int pgx_set_dewarp_coeffs(pgx_ctx *c, int W, int H, const double *coeffs, int ncoeffs)
+{
+    if (!c || !coeffs) return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    if (ncoeffs != 5) return fail(c, PGX_E_BADARG, "You must pass exactly 5 distortion coefficients (ArgumentException)"); // DeWarp.cs:46-48
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return fail(c, PGX_E_BADARG, "map dimensions must fit ushort");
+    const size_t bytes = (size_t)W * H * 8;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, c->d_map.ensure(bytes + 32));
+    pgx_launch_dewarp_map(c->stream, W, H, coeffs, c->d_map.as<int32_t>(), c->d_status);
+    HIPCHK(c, hipGetLastError());
+    c->mapW = W; c->mapH = H; c->map_set = true;
+    return sync_status(c);
+}
+
+int pgx_get_dewarp_map(pgx_ctx *c, int32_t *uv_out, int W, int H)
+{
+    if (!c || !uv_out) return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    if (!c->map_set) return fail(c, PGX_E_NOT_CONFIGURED, "no dewarp map is set");
+    if (W != c->mapW || H != c->mapH) return fail(c, PGX_E_DIM_MISMATCH, "map is %dx%d, asked for %dx%d", c->mapW, c->mapH, W, H);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(uv_out, c->d_map.p, (size_t)W * H * 8, hipMemcpyDeviceToHost));
+    return PGX_OK;
+}
+
 int pgx_set_brief_pairs(pgx_ctx *c, const int32_t *pairs, int P)
 {
     if (!c) return PGX_E_BADARG;

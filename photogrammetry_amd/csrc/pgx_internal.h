@@ -139,6 +139,7 @@ struct ProfScope {
 // k_image.hip
 void pgx_launch_dewarp_gray(hipStream_t s, const uint16_t *rgba, const int32_t *map_uv, int F, int W, int H,
                             float *gray, uint16_t *dewarped, int *status);
+void pgx_launch_dewarp_map(hipStream_t s, int W, int H, const double *k /*[5]*/, int32_t *map_uv, int *status);
 
 // k_fast.hip
 size_t pgx_fast_seg_count(int W, int H);   // segments per frame

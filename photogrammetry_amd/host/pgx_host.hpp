@@ -96,6 +96,18 @@ class DeWarp {
             throw ArgumentException("GetDistortionMatrix");
         return m;
     }
+    // the same table built on the device and left there (no upload); ApplyDistortionMatOnDevice then uses it
+    void InitializeOnDevice() const
+    {
+        if (o_.DistortionCoefficients.size() != 5) throw ArgumentException("You must pass exactly 5 distortion coefficients");
+        ctx_.check(pgx_set_dewarp_coeffs(ctx_.get(), o_.Width, o_.Height, o_.DistortionCoefficients.data(), 5));
+    }
+    Matrix<Uv> GetDeviceDistortionMatrix() const
+    {
+        Matrix<Uv> m(o_.Width, o_.Height);
+        ctx_.check(pgx_get_dewarp_map(ctx_.get(), reinterpret_cast<int32_t *>(m.data.data()), o_.Width, o_.Height));
+        return m;
+    }
     Matrix<Rgba64> ApplyDistortionMat(const Matrix<Rgba64> &image, const Matrix<Uv> &distortionMatrix) const
     {
         ctx_.check(pgx_set_dewarp_map(ctx_.get(), reinterpret_cast<const int32_t *>(distortionMatrix.data.data()),

@@ -408,3 +408,25 @@ def test_detect_synthetic_vs_oracle(engine, W, H, radius, with_map):
     assert kp["value"].tobytes() == kept["value"].tobytes()
     assert (desc == cref.brief(g, np.stack([kept["x"], kept["y"]], 1), pairs)).all()
     engine.set_dewarp_map(None)
+
+
+@pytest.mark.parametrize("W,H,coeffs", [(451, 383, [3e-4, 1e-7, 0, 0, 0]), (1920, 1080, [3e-4, 1e-7, 0, 0, 0]),
+                                        (640, 480, [1e-4, 2e-7, 1e-3, 0, 0]), (97, 61, [1e-3, 5e-7, 0, 0, 0])])
+def test_dewarp_map_built_on_device(engine, W, H, coeffs):
+    """pgx_set_dewarp_coeffs = DeWarp.GetDistortionMatrix on the device.  Same float64 formulas as the host
+    builder; the device libm differs in the last ulp, so a truncated coordinate may differ by one at isolated
+    pixels ("+-1 px, unpinned")."""
+    host = pg.build_dewarp_map(W, H, coeffs)
+    assert (host == cref.build_distortion_matrix(W, H, coeffs)).all()
+    engine.set_dewarp_coeffs(W, H, coeffs)
+    dev = engine.get_dewarp_map(W, H)
+    diff = np.abs(dev.astype(np.int64) - host.astype(np.int64))
+    assert diff.max() <= 1
+    assert (diff != 0).any(axis=2).mean() < 2e-3
+    # the device-built table drives the dewarp like an uploaded one
+    frame = synth.make_frame(W, H, seed=9)
+    if dev.min() >= 0 and (dev[..., 0] < W).all() and (dev[..., 1] < H).all():
+        assert (engine.dewarp(frame) == cref.apply_distortion(frame, dev)).all()
+    with pytest.raises(pg.ArgumentException):
+        engine.set_dewarp_coeffs(W, H, [1.0, 2.0, 3.0])          # DeWarp.cs:46-48
+    engine.set_dewarp_map(None)
