@@ -55,12 +55,20 @@ def make_inputs(pairs_per_step, rank, cache_dir="/tmp/pgx_bench_cache"):
     for b in range(nb):
         seed = 1234 + 1000 * rank + b
         path = os.path.join(cache_dir, "frame_%dx%d_%d.npy" % (W, H, seed))
+        f0 = None
         if os.path.exists(path):
-            f0 = np.load(path)
-        else:
+            try:
+                f0 = np.load(path)
+                if f0.shape != (H, W, 4) or f0.dtype != np.uint16:
+                    f0 = None
+            except (OSError, ValueError):
+                f0 = None   # a torn file from an interrupted run: regenerate
+        if f0 is None:
             f0 = synth.make_frame(W, H, seed=seed, n_shapes=20000)
             try:
-                np.save(path, f0)
+                tmp = "%s.%d.tmp.npy" % (path, os.getpid())
+                np.save(tmp, f0)
+                os.replace(tmp, path)   # atomic: another rank or run never sees a partial file
             except OSError:
                 pass
         bases.append(f0)
