@@ -742,6 +742,7 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
         __syncthreads();
         uint32_t *cur = P.listA, *nxt = P.listB;
         int n_live = (int)sh_cnt;
+        const int n_open0 = n_live;
         int round = round0;
         __syncthreads();
         while (n_live > 0) {
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
             }
             __syncthreads();
             round++;
-            if (round - round0 > (1 << 22)) { // every round closes at least the best open cell; anything else is a bug
+            if (round - round0 > n_open0 + 16) { // every round closes at least the best open cell; anything else is a bug
                 if (tid == 0) atomicOr(status, (int)PGX_ST_INTERNAL);
                 break;
             }
