@@ -383,7 +383,7 @@ __device__ __forceinline__ uint32_t run_pos(const Runs &R, uint32_t fi)
     return pos;
 }
 
-constexpr int NB_REG = 4; // neighbour records per lane and pass (256 neighbours)
+constexpr int NB_REG = 2; // neighbour records per lane and pass (128 neighbours)
 
 __device__ __forceinline__ unsigned long long sort_key(int score, uint32_t idx)
 {
@@ -487,9 +487,10 @@ __global__ __launch_bounds__(256) void k_nms_phase_a(NmsLayout L, int radius, in
 // The accepted set of a round is exactly the locally-best set of the plain formulation above.
 __device__ __forceinline__ void champ_cell(const NmsPtrs &P, const NmsLayout &L, int c)
 {
-    if (P.cell_und[c] == 0) return; // its grid entry is already {0,0}
+    const uint32_t und = P.cell_und[c]; // the three per-cell words in one round trip, not three
     uint32_t h = P.cell_fill[c];
     const uint32_t e = P.cell_start[c + 1];
+    if (und == 0) return; // its grid entry is already {0,0}
     uint4 r = make_uint4(0, 0, 0, ST_SUPPRESSED);
     while (h < e) { // four records per trip: the walk is a chain of dependent L2 round trips otherwise
         const uint4 none = make_uint4(0, 0, 0, ST_SUPPRESSED);
