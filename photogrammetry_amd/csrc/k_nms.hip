@@ -230,6 +230,90 @@ __global__ __launch_bounds__(256) void k_nms_scatter(const uint32_t *__restrict_
 // One thread per cell: MODE 0 counts the hits of its cs x cs pixels into cell_fill, MODE 1 (after the
 // cell scan) writes their records at cell_start[c]... in raster order.  The input index of a hit is its
 // raster rank = segoff + popcount(lower bits), exactly what k_fast_compact wrote into the raw list.
+// 8-pixel cells (r = 10..21, the common case): the cell's 8x8 bits of each plane are packed into ONE 64-bit word
+// (bit = 8 * row + column, raster order inside the cell) right after the loads, so the row data lives in 14
+// registers instead of 56 and eight wavefronts per SIMD hide the load latency.  Own kernel: inside the general
+// one its register count would still be the general path's.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_nms_bin_planes8(const unsigned long long *__restrict__ seg_all,
+                                                         const uint32_t *__restrict__ segoff_all, int W, int H, int ntx,
+                                                         int n_cap, NmsLayout L, unsigned char *ws_all, size_t ws_stride)
+{
+    const int f = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= L.ncell) return;
+    NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
+    const int cy = c / L.gw, cx = c - cy * L.gw;
+    const int x0 = cx * 8, tx = x0 >> 6, bo = x0 & 63;
+    const int y0 = cy * 8, y1 = (y0 + 8 < H) ? y0 + 8 : H;
+    const size_t nseg = (size_t)H * ntx;
+    const unsigned long long *seg = seg_all + (size_t)f * nseg * 4;
+    const uint32_t *segoff = segoff_all + (size_t)f * nseg;
+    unsigned long long A0 = 0, A1 = 0, A2 = 0;
+    uint32_t base[8];
+    {
+        ulonglong2 rp8[8];
+        unsigned long long rb8[8];
+        uint32_t so8[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { // all loads first
+            const bool ok = y0 + i < y1;
+            const size_t si = (size_t)(ok ? y0 + i : y0) * ntx + tx;
+            rp8[i] = *reinterpret_cast<const ulonglong2 *>(seg + si * 4);
+            rb8[i] = seg[si * 4 + 2];
+            so8[i] = segoff[si];
+            if (!ok) { rp8[i] = make_ulonglong2(0ull, 0ull); rb8[i] = 0ull; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const unsigned long long any = rp8[i].x | rp8[i].y | rb8[i];
+            base[i] = so8[i] + (uint32_t)__popcll(any & ((1ull << bo) - 1ull)); // raster rank of the row slice's first hit
+            // hits past the raw capacity are dropped everywhere (PGX_E_CAPACITY is raised): keep the first n_cap - base
+            uint32_t keep = (uint32_t)(any >> bo) & 0xFFu;
+            const uint32_t room = base[i] < (uint32_t)n_cap ? (uint32_t)n_cap - base[i] : 0u;
+            while ((uint32_t)__popc(keep) > room) keep &= ~(1u << (31 - __builtin_clz(keep)));
+            A0 |= ((rp8[i].x >> bo) & (unsigned long long)keep) << (8 * i);
+            A1 |= ((rp8[i].y >> bo) & (unsigned long long)keep) << (8 * i);
+            A2 |= ((rb8[i] >> bo) & (unsigned long long)keep) << (8 * i);
+        }
+    }
+    const unsigned long long any64 = A0 | A1 | A2;
+    if (MODE == 0) { P.cell_fill[c] = (uint32_t)__popcll(any64); return; }
+    const uint32_t first = P.cell_start[c];
+    // codes: 5 = 101, 4 = 100, 3 = 011, 2 = 010, 1 = 001 (planes A2 A1 A0); MODE 2 = priority order, see below
+    uint32_t q5 = first, q4 = first, q3 = first, q2 = first, q1 = first;
+    if (MODE == 2) {
+        const uint32_t c5 = (uint32_t)__popcll(A2 & A0), c4 = (uint32_t)__popcll(A2 & ~A0);
+        const uint32_t c3 = (uint32_t)__popcll(~A2 & A1 & A0), c2 = (uint32_t)__popcll(~A2 & A1 & ~A0);
+        q4 += c5; q3 += c5 + c4; q2 += c5 + c4 + c3; q1 += c5 + c4 + c3 + c2;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t m = (uint32_t)(any64 >> (8 * i)) & 0xFFu;
+        const uint32_t r0 = (uint32_t)(A0 >> (8 * i)) & 0xFFu, r1 = (uint32_t)(A1 >> (8 * i)) & 0xFFu, r2 = (uint32_t)(A2 >> (8 * i)) & 0xFFu;
+        uint32_t idx = base[i];
+        while (m) {
+            const int l = __builtin_ctz(m);
+            m &= m - 1;
+            const int code = (int)((r0 >> l) & 1u) | ((int)((r1 >> l) & 1u) << 1) | ((int)((r2 >> l) & 1u) << 2);
+            uint32_t at;
+            if (MODE == 2) {
+                at = code == 5 ? q5 : (code == 4 ? q4 : (code == 3 ? q3 : (code == 2 ? q2 : q1)));
+                q5 += code == 5; q4 += code == 4; q3 += code == 3; q2 += code == 2; q1 += code == 1;
+            } else {
+                at = q1++;
+            }
+            P.rec[at] = make_uint4(((uint32_t)(y0 + i) << 16) | (uint32_t)(x0 + l), (uint32_t)(code + 11), idx, ST_UNDECIDED);
+            idx++;
+        }
+    }
+    if (MODE == 2) {
+        uint2 ch = make_uint2(0u, 0u);
+        if (q1 > first) { const uint4 r0 = P.rec[first]; ch = make_uint2(champ_key(r0.y, r0.z), r0.x); }
+        P.champ[(cy + L.R) * L.cgw + cx + L.R] = ch;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_nms_bin_planes(const unsigned long long *__restrict__ seg_all,
                                                         const uint32_t *__restrict__ segoff_all, int W, int H, int ntx,
@@ -948,10 +1032,12 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
         const dim3 bgrid((L.ncell + 255) / 256, F);
         const int ntx = (W + 63) / 64;
         hipLaunchKernelGGL(k_nms_zero, dim3((L.ncell + 256) / 256, F), dim3(256), 0, s, L, ws, ws_stride);
-        if (planes) hipLaunchKernelGGL(k_nms_bin_planes<0>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
+        if (planes && L.cs == 8) hipLaunchKernelGGL(k_nms_bin_planes8<0>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
+        else if (planes) hipLaunchKernelGGL(k_nms_bin_planes<0>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
         else hipLaunchKernelGGL(k_nms_count, pgrid, dim3(256), 0, s, raw_xy, n_raw, n_cap, L, ws, ws_stride);
         hipLaunchKernelGGL(k_nms_cellscan, dim3(F), dim3(NT), 0, s, L, ws, ws_stride);
-        if (L.champ) hipLaunchKernelGGL(k_nms_bin_planes<2>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
+        if (L.champ && L.cs == 8) hipLaunchKernelGGL(k_nms_bin_planes8<2>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
+        else if (L.champ) hipLaunchKernelGGL(k_nms_bin_planes<2>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
         else if (planes) hipLaunchKernelGGL(k_nms_bin_planes<1>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
         else hipLaunchKernelGGL(k_nms_scatter, pgrid, dim3(256), 0, s, raw_xy, raw_score, n_raw, n_cap, L, ws, ws_stride);
         static const int wide_rounds = [] { const char *e = getenv("PGX_NMS_ROUNDS"); int v = e ? atoi(e) : WIDE_ROUNDS; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
