@@ -576,17 +576,15 @@ __device__ __forceinline__ void champ_cell(const NmsPtrs &P, const NmsLayout &L,
     const uint32_t e = P.cell_start[c + 1];
     if (und == 0) return; // its grid entry is already {0,0}
     uint4 r = make_uint4(0, 0, 0, ST_SUPPRESSED);
-    while (h < e) { // four records per trip: the walk is a chain of dependent L2 round trips otherwise
-        const uint4 none = make_uint4(0, 0, 0, ST_SUPPRESSED);
-        const uint4 r0 = P.rec[h];
-        const uint4 r1 = h + 1 < e ? P.rec[h + 1] : none;
-        const uint4 r2 = h + 2 < e ? P.rec[h + 2] : none;
-        const uint4 r3 = h + 3 < e ? P.rec[h + 3] : none;
-        if (r0.w == ST_UNDECIDED) { r = r0; break; }
-        if (r1.w == ST_UNDECIDED) { r = r1; h += 1; break; }
-        if (r2.w == ST_UNDECIDED) { r = r2; h += 2; break; }
-        if (r3.w == ST_UNDECIDED) { r = r3; h += 3; break; }
-        h += 4;
+    while (h < e) { // eight records per trip: the walk is a chain of dependent L2 round trips otherwise
+        uint4 rr[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) rr[k] = h + k < e ? P.rec[h + k] : make_uint4(0, 0, 0, ST_SUPPRESSED);
+        int hit = -1;
+#pragma unroll
+        for (int k = 7; k >= 0; k--) if (rr[k].w == ST_UNDECIDED) { hit = k; r = rr[k]; }
+        if (hit >= 0) { h += (uint32_t)hit; break; }
+        h += 8;
     }
     if (h > e) h = e;
     const int cy = c / L.gw, cx = c - cy * L.gw;
