@@ -434,7 +434,8 @@ __global__ __launch_bounds__(256) void k_nms_bin_planes(const unsigned long long
 constexpr int MAXRUN = 7;
 struct Runs { uint32_t q[MAXRUN], l[MAXRUN], total; };
 
-__device__ __forceinline__ Runs cell_runs(const NmsPtrs &P, const NmsLayout &L, int cx, int cy)
+// `cs` = the cell offsets: P.cell_start (bias 0) or an LDS copy of the slice [bias, ...) a workgroup needs
+__device__ __forceinline__ Runs cell_runs_from(const uint32_t *cs, int bias, const NmsLayout &L, int cx, int cy)
 {
     Runs R;
     const int cx0 = cx - L.R > 0 ? cx - L.R : 0, cx1 = cx + L.R < L.gw ? cx + L.R : L.gw - 1;
@@ -444,13 +445,18 @@ __device__ __forceinline__ Runs cell_runs(const NmsPtrs &P, const NmsLayout &L, 
         const int yy = cy - L.R + j;
         uint32_t q = 0, len = 0;
         if (j <= 2 * L.R && yy >= 0 && yy < L.gh) {
-            q = P.cell_start[yy * L.gw + cx0];
-            len = P.cell_start[yy * L.gw + cx1 + 1] - q;
+            q = cs[yy * L.gw + cx0 - bias];
+            len = cs[yy * L.gw + cx1 + 1 - bias] - q;
         }
         R.q[j] = q; R.l[j] = len;
         R.total += len;
     }
     return R;
+}
+
+__device__ __forceinline__ Runs cell_runs(const NmsPtrs &P, const NmsLayout &L, int cx, int cy)
+{
+    return cell_runs_from(P.cell_start, 0, L, cx, cy);
 }
 
 __device__ __forceinline__ uint32_t run_pos(const Runs &R, uint32_t fi)
@@ -609,7 +615,8 @@ __global__ __launch_bounds__(256) void k_nms_champ(NmsLayout L, unsigned char *w
 
 // called by whole wavefronts: lane = one cell (c, valid when incell)
 template <int RR>
-__device__ __forceinline__ void phase_c_wave(const NmsPtrs &P, const NmsLayout &L, int radius, int round, int c, bool incell)
+__device__ __forceinline__ void phase_c_wave(const NmsPtrs &P, const NmsLayout &L, int radius, int round, int c, bool incell,
+                                             const uint32_t *cs, int cs_bias /* cell offsets: P.cell_start, 0 or an LDS slice */)
 {
     const int lane = threadIdx.x & 63;
     const int cc = incell ? c : 0;
@@ -650,7 +657,7 @@ __device__ __forceinline__ void phase_c_wave(const NmsPtrs &P, const NmsLayout &
         todo &= todo - 1;
         const uint32_t ckey = (uint32_t)__shfl((int)me.x, k), cxy = (uint32_t)__shfl((int)me.y, k);
         const int kx = __shfl(cx, k), ky = __shfl(cy, k);
-        const Runs R = cell_runs(P, L, kx, ky);
+        const Runs R = cell_runs_from(cs, cs_bias, L, kx, ky);
         if ((deep >> k) & 1ull) {
             bool h = false;
             for (uint32_t nb0 = 0; nb0 < R.total; nb0 += 64 * NB_REG) {
@@ -700,14 +707,35 @@ __device__ __forceinline__ void phase_c_wave(const NmsPtrs &P, const NmsLayout &
     }
 }
 
-template <int RR>
+constexpr int CS_LDS_MAX = 4096; // cell offsets a phase-C workgroup may stage (16 KiB)
+
+// STAGE (first round only): the exact test and the suppression walk start with the run table of a centre's
+// (2R+1)^2 block, ten cell offsets.  The 256 cells of a workgroup only ever need the offsets of their own grid
+// rows +-R, a few KB: staged in LDS once, so that per centre the dependent global round trips are "records" only.
+// Pays only while a workgroup has dozens of centres (round 0); later rounds have few and skip it.
+template <int RR, bool STAGE>
 __global__ __launch_bounds__(256) void k_nms_phase_c(NmsLayout L, int radius, int round, unsigned char *ws_all,
                                                      size_t ws_stride)
 {
+    __shared__ uint32_t cs_lds[STAGE ? CS_LDS_MAX : 1];
     const int f = blockIdx.y;
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c0 = blockIdx.x * 256;
+    const int c = c0 + threadIdx.x;
     const NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
-    phase_c_wave<RR>(P, L, radius, round, c, c < L.ncell);
+    if (STAGE) {
+        const int clast = c0 + 255 < L.ncell ? c0 + 255 : L.ncell - 1;
+        int ylo = c0 / L.gw - RR, yhi = clast / L.gw + RR;
+        ylo = ylo < 0 ? 0 : ylo;
+        yhi = yhi >= L.gh ? L.gh - 1 : yhi;
+        const int lo = ylo * L.gw, n = (yhi + 1) * L.gw + 1 - lo; // flat slice [lo, lo + n) of cell_start
+        if (n <= CS_LDS_MAX) {                                     // block-uniform
+            for (int i = threadIdx.x; i < n; i += 256) cs_lds[i] = P.cell_start[lo + i];
+            __syncthreads();
+            phase_c_wave<RR>(P, L, radius, round, c, c < L.ncell, cs_lds, lo); // separate call: the address space stays known
+            return;
+        }
+    }
+    phase_c_wave<RR>(P, L, radius, round, c, c < L.ncell, P.cell_start, 0);
 }
 
 // Phase B, one wavefront per NEWLY accepted point (a few thousand per frame over all rounds): retire
@@ -843,8 +871,8 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
                 const int i = base + tid;
                 const bool in = i < n_live;
                 const int c = in ? (int)cur[i] : 0;
-                if (L.R <= 2) phase_c_wave<2>(P, L, radius, round, c, in);
-                else phase_c_wave<3>(P, L, radius, round, c, in);
+                if (L.R <= 2) phase_c_wave<2>(P, L, radius, round, c, in, P.cell_start, 0);
+                else phase_c_wave<3>(P, L, radius, round, c, in, P.cell_start, 0);
             }
             __syncthreads();
             round++;
@@ -1043,8 +1071,13 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
         for (int r = 0; r < wide_rounds; r++) {
             if (L.champ) {
                 if (r > 0) hipLaunchKernelGGL(k_nms_champ, bgrid, dim3(256), 0, s, L, ws, ws_stride);
-                if (L.R <= 2) hipLaunchKernelGGL(k_nms_phase_c<2>, bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
-                else hipLaunchKernelGGL(k_nms_phase_c<3>, bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
+                if (L.R <= 2) {
+                    if (r == 0) hipLaunchKernelGGL((k_nms_phase_c<2, true>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
+                    else hipLaunchKernelGGL((k_nms_phase_c<2, false>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
+                } else {
+                    if (r == 0) hipLaunchKernelGGL((k_nms_phase_c<3, true>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
+                    else hipLaunchKernelGGL((k_nms_phase_c<3, false>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
+                }
             } else {
                 hipLaunchKernelGGL(k_nms_phase_a, cgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
             }
