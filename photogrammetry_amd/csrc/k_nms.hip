@@ -709,10 +709,10 @@ __device__ __forceinline__ void phase_c_wave(const NmsPtrs &P, const NmsLayout &
 
 constexpr int CS_LDS_MAX = 4096; // cell offsets a phase-C workgroup may stage (16 KiB)
 
-// STAGE (first round only): the exact test and the suppression walk start with the run table of a centre's
+// STAGE (first two rounds only): the exact test and the suppression walk start with the run table of a centre's
 // (2R+1)^2 block, ten cell offsets.  The 256 cells of a workgroup only ever need the offsets of their own grid
 // rows +-R, a few KB: staged in LDS once, so that per centre the dependent global round trips are "records" only.
-// Pays only while a workgroup has dozens of centres (round 0); later rounds have few and skip it.
+// Pays only while a workgroup has dozens of centres (rounds 0 and 1); later rounds have few and skip it.
 template <int RR, bool STAGE>
 __global__ __launch_bounds__(256) void k_nms_phase_c(NmsLayout L, int radius, int round, unsigned char *ws_all,
                                                      size_t ws_stride)
@@ -1072,10 +1072,10 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
             if (L.champ) {
                 if (r > 0) hipLaunchKernelGGL(k_nms_champ, bgrid, dim3(256), 0, s, L, ws, ws_stride);
                 if (L.R <= 2) {
-                    if (r == 0) hipLaunchKernelGGL((k_nms_phase_c<2, true>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
+                    if (r <= 1) hipLaunchKernelGGL((k_nms_phase_c<2, true>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
                     else hipLaunchKernelGGL((k_nms_phase_c<2, false>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
                 } else {
-                    if (r == 0) hipLaunchKernelGGL((k_nms_phase_c<3, true>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
+                    if (r <= 1) hipLaunchKernelGGL((k_nms_phase_c<3, true>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
                     else hipLaunchKernelGGL((k_nms_phase_c<3, false>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
                 }
             } else {
