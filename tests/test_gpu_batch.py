@@ -223,3 +223,31 @@ def test_detect_4k_frame_vs_oracle(engine):
     assert kp[:n, 3].view(np.float32).tobytes() == kept["value"].tobytes()
     assert (d_desc.cpu().numpy().view(np.uint32)[0, :n] == edesc).all()
     engine.set_dewarp_map(None)
+
+
+@pytest.mark.parametrize("radius", [10, 16, 21, 33])
+def test_detect_dense_noise_frame_vs_oracle(engine, radius):
+    """White-noise frame: a large share of the pixels are FAST hits (cells of the NMS grid hold dozens of
+    records, neighbourhoods need several passes, every score level is populated)."""
+    W, H, CAP, RAW = 640, 480, 8192, 1 << 19
+    T = np.float32(0.1)
+    rng = np.random.default_rng(77)
+    frame = rng.integers(0, 65536, (H, W, 4), dtype=np.uint16)
+    pairs = pg.make_brief_pairs(1, 50, 256)
+    engine.set_brief_pairs(pairs)
+    engine.set_detect_params(T, radius)
+    engine.set_capacity(RAW, CAP)
+    engine.set_dewarp_map(None)
+    d_frames = torch.from_numpy(frame[None]).to(DEV)
+    d_kp = torch.zeros((1, CAP, 4), dtype=torch.int32, device=DEV)
+    d_desc = torch.zeros((1, CAP, 8), dtype=torch.int32, device=DEV)
+    d_counts = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d_nraw = torch.zeros(1, dtype=torch.int32, device=DEV)
+    engine.detect_batch_dev(d_frames, 1, W, H, d_kp, d_desc, d_counts, d_nraw, CAP)
+    engine.check_status()
+    kept, edesc, n_raw = _oracle_detect(frame, None, pairs, T, radius, CAP)
+    n = len(kept)
+    assert n_raw > 20000 and int(d_nraw[0]) == n_raw and int(d_counts[0]) == n
+    kp = d_kp.cpu().numpy()[0]
+    assert (kp[:n, 0] == kept["x"]).all() and (kp[:n, 1] == kept["y"]).all() and (kp[:n, 2] == kept["fast_score"]).all()
+    assert (d_desc.cpu().numpy().view(np.uint32)[0, :n] == edesc).all()
