@@ -325,7 +325,7 @@ def main():
                            "mfma_frac_of_peak_on_match_stage": (evals * 2.0 * P / (match_ms * 1e-3)) / I8_MFMA_PEAK_OPS
                            if match_ms else None},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: at N > 1 the other ranks would sit in the barrier
             t1 = time.time()
             result["cpu_baseline"] = cpu_baseline(frames_h, dmap if dmap is not None else
                                                   np.stack(np.meshgrid(np.arange(W), np.arange(H)), axis=2).astype(np.int32),
