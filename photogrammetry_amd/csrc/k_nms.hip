@@ -1041,55 +1041,137 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
 
 size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap, bool planes) { return nms_layout(W, H, radius, n_cap, planes).total; }
 
-void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw, int F,
-                    int n_cap, int W, int H, int radius, void *wsv, size_t ws_stride, uint32_t *order,
-                    int32_t *n_kept, int kp_cap, int *status, const unsigned long long *seg, const uint32_t *segoff)
+namespace {
+
+struct NmsLaunch {
+    hipStream_t s;
+    const uint32_t *raw_xy; const int32_t *raw_score; const int32_t *n_raw;
+    int F, n_cap, W, H, radius;
+    unsigned char *ws; size_t ws_stride;
+    uint32_t *order; int32_t *n_kept; int kp_cap; int *status;
+    const unsigned long long *seg; const uint32_t *segoff;
+    NmsLayout L;
+    bool planes;
+};
+
+void nms_setup(const NmsLaunch &a)
 {
-    if (F <= 0) return;
-    unsigned char *ws = reinterpret_cast<unsigned char *>(wsv);
-    const bool have_planes = seg && segoff;
-    const NmsLayout L = nms_layout(W, H, radius, n_cap, have_planes);
-    const bool rounds = radius >= 0;
-    int wide_rounds_used = 0;
-    const dim3 pgrid((n_cap + 255) / 256, F);
-    const dim3 cgrid((L.ncell + 3) / 4, F);
-    if (rounds) {
-        const bool planes = have_planes && (L.cs == 8 || L.cs == 16 || L.cs == 32 || L.cs == 64);
-        const dim3 bgrid((L.ncell + 255) / 256, F);
-        const int ntx = (W + 63) / 64;
-        hipLaunchKernelGGL(k_nms_zero, dim3((L.ncell + 256) / 256, F), dim3(256), 0, s, L, ws, ws_stride);
-        if (planes && L.cs == 8) hipLaunchKernelGGL(k_nms_bin_planes8<0>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
-        else if (planes) hipLaunchKernelGGL(k_nms_bin_planes<0>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
-        else hipLaunchKernelGGL(k_nms_count, pgrid, dim3(256), 0, s, raw_xy, n_raw, n_cap, L, ws, ws_stride);
-        hipLaunchKernelGGL(k_nms_cellscan, dim3(F), dim3(NT), 0, s, L, ws, ws_stride);
-        if (L.champ && L.cs == 8) hipLaunchKernelGGL(k_nms_bin_planes8<2>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
-        else if (L.champ) hipLaunchKernelGGL(k_nms_bin_planes<2>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
-        else if (planes) hipLaunchKernelGGL(k_nms_bin_planes<1>, bgrid, dim3(256), 0, s, seg, segoff, W, H, ntx, n_cap, L, ws, ws_stride);
-        else hipLaunchKernelGGL(k_nms_scatter, pgrid, dim3(256), 0, s, raw_xy, raw_score, n_raw, n_cap, L, ws, ws_stride);
-        static const int wide_rounds = [] { const char *e = getenv("PGX_NMS_ROUNDS"); int v = e ? atoi(e) : WIDE_ROUNDS; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
-        wide_rounds_used = wide_rounds;
-        for (int r = 0; r < wide_rounds; r++) {
-            if (L.champ) {
-                if (r > 0) hipLaunchKernelGGL(k_nms_champ, bgrid, dim3(256), 0, s, L, ws, ws_stride);
-                if (L.R <= 2) {
-                    if (r <= 1) hipLaunchKernelGGL((k_nms_phase_c<2, true>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
-                    else hipLaunchKernelGGL((k_nms_phase_c<2, false>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
-                } else {
-                    if (r <= 1) hipLaunchKernelGGL((k_nms_phase_c<3, true>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
-                    else hipLaunchKernelGGL((k_nms_phase_c<3, false>), bgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
-                }
+    const NmsLayout &L = a.L;
+    hipStream_t s = a.s;
+    const dim3 pgrid((a.n_cap + 255) / 256, a.F);
+    const dim3 bgrid((L.ncell + 255) / 256, a.F);
+    const int ntx = (a.W + 63) / 64;
+    hipLaunchKernelGGL(k_nms_zero, dim3((L.ncell + 256) / 256, a.F), dim3(256), 0, s, L, a.ws, a.ws_stride);
+    if (a.planes && L.cs == 8) hipLaunchKernelGGL(k_nms_bin_planes8<0>, bgrid, dim3(256), 0, s, a.seg, a.segoff, a.W, a.H, ntx, a.n_cap, L, a.ws, a.ws_stride);
+    else if (a.planes) hipLaunchKernelGGL(k_nms_bin_planes<0>, bgrid, dim3(256), 0, s, a.seg, a.segoff, a.W, a.H, ntx, a.n_cap, L, a.ws, a.ws_stride);
+    else hipLaunchKernelGGL(k_nms_count, pgrid, dim3(256), 0, s, a.raw_xy, a.n_raw, a.n_cap, L, a.ws, a.ws_stride);
+    hipLaunchKernelGGL(k_nms_cellscan, dim3(a.F), dim3(NT), 0, s, L, a.ws, a.ws_stride);
+    if (L.champ && L.cs == 8) hipLaunchKernelGGL(k_nms_bin_planes8<2>, bgrid, dim3(256), 0, s, a.seg, a.segoff, a.W, a.H, ntx, a.n_cap, L, a.ws, a.ws_stride);
+    else if (L.champ) hipLaunchKernelGGL(k_nms_bin_planes<2>, bgrid, dim3(256), 0, s, a.seg, a.segoff, a.W, a.H, ntx, a.n_cap, L, a.ws, a.ws_stride);
+    else if (a.planes) hipLaunchKernelGGL(k_nms_bin_planes<1>, bgrid, dim3(256), 0, s, a.seg, a.segoff, a.W, a.H, ntx, a.n_cap, L, a.ws, a.ws_stride);
+    else hipLaunchKernelGGL(k_nms_scatter, pgrid, dim3(256), 0, s, a.raw_xy, a.raw_score, a.n_raw, a.n_cap, L, a.ws, a.ws_stride);
+}
+
+// whole-chip rounds [r0, r0 + n)
+void nms_rounds(const NmsLaunch &a, int r0, int n)
+{
+    const NmsLayout &L = a.L;
+    hipStream_t s = a.s;
+    const dim3 bgrid((L.ncell + 255) / 256, a.F);
+    const dim3 cgrid((L.ncell + 3) / 4, a.F);
+    for (int r = r0; r < r0 + n; r++) {
+        if (L.champ) {
+            if (r > 0) hipLaunchKernelGGL(k_nms_champ, bgrid, dim3(256), 0, s, L, a.ws, a.ws_stride);
+            if (L.R <= 2) {
+                if (r <= 1) hipLaunchKernelGGL((k_nms_phase_c<2, true>), bgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride);
+                else hipLaunchKernelGGL((k_nms_phase_c<2, false>), bgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride);
             } else {
-                hipLaunchKernelGGL(k_nms_phase_a, cgrid, dim3(256), 0, s, L, radius, r, ws, ws_stride);
+                if (r <= 1) hipLaunchKernelGGL((k_nms_phase_c<3, true>), bgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride);
+                else hipLaunchKernelGGL((k_nms_phase_c<3, false>), bgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride);
             }
-            if (!L.champ) hipLaunchKernelGGL(k_nms_push, dim3(r == 0 ? 256 : 64, F), dim3(256), 0, s, L, radius, r, ws, ws_stride);
+        } else {
+            hipLaunchKernelGGL(k_nms_phase_a, cgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride);
+            hipLaunchKernelGGL(k_nms_push, dim3(r == 0 ? 256 : 64, a.F), dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride);
         }
     }
+}
+
+void nms_finish(const NmsLaunch &a, int round0)
+{
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nms_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(SORT_LDS_MAX * 8));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_nms_tail, dim3(F), dim3(NT), SORT_LDS_MAX * 8, s, raw_score, n_raw, n_cap, L, radius, ws,
-                       ws_stride, order, n_kept, kp_cap, status, rounds ? wide_rounds_used : 0);
+    hipLaunchKernelGGL(k_nms_tail, dim3(a.F), dim3(NT), SORT_LDS_MAX * 8, a.s, a.raw_score, a.n_raw, a.n_cap, a.L, a.radius, a.ws,
+                       a.ws_stride, a.order, a.n_kept, a.kp_cap, a.status, round0);
+}
+
+NmsLaunch nms_args(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw, int F, int n_cap,
+                   int W, int H, int radius, void *wsv, size_t ws_stride, uint32_t *order, int32_t *n_kept, int kp_cap,
+                   int *status, const unsigned long long *seg, const uint32_t *segoff)
+{
+    NmsLaunch a;
+    a.s = s; a.raw_xy = raw_xy; a.raw_score = raw_score; a.n_raw = n_raw; a.F = F; a.n_cap = n_cap; a.W = W; a.H = H;
+    a.radius = radius; a.ws = reinterpret_cast<unsigned char *>(wsv); a.ws_stride = ws_stride; a.order = order;
+    a.n_kept = n_kept; a.kp_cap = kp_cap; a.status = status; a.seg = seg; a.segoff = segoff;
+    const bool have_planes = seg && segoff;
+    a.L = nms_layout(W, H, radius, n_cap, have_planes);
+    a.planes = have_planes && (a.L.cs == 8 || a.L.cs == 16 || a.L.cs == 32 || a.L.cs == 64);
+    return a;
+}
+
+int wide_rounds_default()
+{
+    static const int v = [] { const char *e = getenv("PGX_NMS_ROUNDS"); int r = e ? atoi(e) : WIDE_ROUNDS; return r < 1 ? 1 : (r > 64 ? 64 : r); }();
+    return v;
+}
+
+} // namespace
+
+// asynchronous form (fused detect path): a fixed number of whole-chip rounds, the tail kernel finishes
+void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw, int F,
+                    int n_cap, int W, int H, int radius, void *wsv, size_t ws_stride, uint32_t *order,
+                    int32_t *n_kept, int kp_cap, int *status, const unsigned long long *seg, const uint32_t *segoff)
+{
+    if (F <= 0) return;
+    const NmsLaunch a = nms_args(s, raw_xy, raw_score, n_raw, F, n_cap, W, H, radius, wsv, ws_stride, order, n_kept, kp_cap,
+                                 status, seg, segoff);
+    int used = 0;
+    if (radius >= 0) {
+        nms_setup(a);
+        // the general path's tail is a plain serial finish: give it fewer leftovers than the champion tail needs
+        used = a.L.champ ? wide_rounds_default() : wide_rounds_default() + 6;
+        nms_rounds(a, 0, used);
+    }
+    nms_finish(a, used);
+}
+
+// synchronous form (stage API, one list, general path): whole-chip rounds until a round accepts nothing -- then
+// everything is decided, since every round accepts at least the best undecided point.  The host reads one
+// counter per batch of rounds; long dependency chains (large r on dense lists need 50-100 rounds) never reach
+// the serial tail, which only sorts.
+hipError_t pgx_launch_nms_sync(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw,
+                               int n_cap, int W, int H, int radius, void *wsv, size_t ws_stride, uint32_t *order,
+                               int32_t *n_kept, int kp_cap, int *status)
+{
+    const NmsLaunch a = nms_args(s, raw_xy, raw_score, n_raw, 1, n_cap, W, H, radius, wsv, ws_stride, order, n_kept, kp_cap,
+                                 status, nullptr, nullptr);
+    int r0 = 0;
+    if (radius >= 0) {
+        nms_setup(a);
+        const int batch = 16;
+        const uint32_t *counters = reinterpret_cast<const uint32_t *>(a.ws + a.L.off_counters);
+        for (; r0 < (1 << 20); r0 += batch) {
+            nms_rounds(a, r0, batch);
+            uint32_t last = 0; // accepted in the batch's last round (k_nms_push leaves that round's counter in place)
+            hipError_t e = hipMemcpyAsync(&last, counters + ((r0 + batch - 1) & 1), 4, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return e;
+            if (last == 0) { r0 += batch; break; }
+        }
+    }
+    nms_finish(a, r0);
+    return hipGetLastError();
 }

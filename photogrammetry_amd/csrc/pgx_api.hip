@@ -395,8 +395,9 @@ int pgx_nms(pgx_ctx *c, const pgx_keypoint *kps, int n, int W, int H, int32_t *o
     HIPCHK(c, hipMemcpyAsync(c->st_a.p, xy.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->st_b.p, sc.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->st_d.p, &n, 4, hipMemcpyHostToDevice, c->stream));
-    pgx_launch_nms(c->stream, c->st_a.as<uint32_t>(), c->st_b.as<int32_t>(), c->st_d.as<int32_t>(), 1, n, W, H,
-                   c->radius, c->ws_nms.p, wsb, c->st_c.as<uint32_t>(), c->st_d.as<int32_t>() + 1, n, c->d_status);
+    HIPCHK(c, pgx_launch_nms_sync(c->stream, c->st_a.as<uint32_t>(), c->st_b.as<int32_t>(), c->st_d.as<int32_t>(), n, W, H,
+                                  c->radius, c->ws_nms.p, wsb, c->st_c.as<uint32_t>(), c->st_d.as<int32_t>() + 1, n,
+                                  c->d_status));
     int nk = 0;
     HIPCHK(c, hipMemcpyAsync(&nk, c->st_d.as<int32_t>() + 1, 4, hipMemcpyDeviceToHost, c->stream));
     int rc = sync_status(c);

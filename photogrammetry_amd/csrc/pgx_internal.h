@@ -155,6 +155,10 @@ void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_sc
                     uint32_t *order /*[F][kp_cap]*/, int32_t *n_kept /*[F]*/, int kp_cap, int *status,
                     const unsigned long long *seg = nullptr /* FAST planes: enables atomic-free binning */,
                     const uint32_t *segoff = nullptr);
+// stage API (one list, host waits): whole-chip rounds until nothing is left undecided, see k_nms.hip
+hipError_t pgx_launch_nms_sync(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw,
+                               int n_cap, int W, int H, int radius, void *ws, size_t ws_stride, uint32_t *order,
+                               int32_t *n_kept, int kp_cap, int *status);
 
 // k_brief.hip
 void pgx_launch_brief(hipStream_t s, const float *gray, int F, int W, int H,

@@ -430,3 +430,22 @@ def test_dewarp_map_built_on_device(engine, W, H, coeffs):
     with pytest.raises(pg.ArgumentException):
         engine.set_dewarp_coeffs(W, H, [1.0, 2.0, 3.0])          # DeWarp.cs:46-48
     engine.set_dewarp_map(None)
+
+
+def test_nms_stage_api_full_size_list(engine):
+    """pgx_nms on the raw list of a whole 1920x1080 frame (1.5e5 points) at the reference's shipped radius: long
+    dependency chains (dozens of rounds).  Exact, and finished by whole-chip rounds rather than by the serial
+    tail (which took seconds here): the time bound is loose but catches that regression."""
+    import time
+    W, H = 1920, 1080
+    g = cref.gray(synth.make_frame(W, H, seed=3, n_shapes=20000))
+    raw = cref.detect(g, np.float32(0.1))
+    assert len(raw) > 100000
+    for radius in (50, 23):
+        engine.set_detect_params(0.1, radius)
+        engine.nms(raw, W, H)
+        t0 = time.perf_counter()
+        order = engine.nms(raw, W, H)
+        dt = time.perf_counter() - t0
+        assert (order == cref.nms(raw, radius)).all()
+        assert dt < 0.25, dt
