@@ -282,7 +282,8 @@ def main():
                                    "(%d raw hits, %d survivors per step)" % (n_raw_tot, n_kept_tot))
         if "brief" in kern:
             rooflines["brief"] = hbm("brief", (2.0 * P * 4 + 48.0) * n_kept_tot,
-                                     "L2-latency-bound gathers: 2*P*4 B gathered + 48 B written per survivor")
+                                     "2*P*4 B gathered + 48 B written per survivor; the kernel is bound by the L2->L1 line rate of fully divergent "
+                                     "4-byte gathers (one 128-B line per sample), not by HBM")
         if "ham_argmin" in kern:
             ops = evals * 2.0 * P
             t = kern["ham_argmin"]["ms_per_step"] * 1e-3
