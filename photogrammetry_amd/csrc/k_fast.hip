@@ -243,13 +243,16 @@ size_t pgx_fast_seg_count(int W, int H) { return (size_t)H * ((W + TW - 1) / TW)
 
 void pgx_launch_fast(hipStream_t s, const float *gray, int F, int W, int H, float T,
                      unsigned long long *seg, uint32_t *segoff, int32_t *n_raw, uint32_t *raw_xy,
-                     int32_t *raw_score, int raw_cap, int *status)
+                     int32_t *raw_score, int raw_cap, int *status, bool compact)
 {
     if (F <= 0 || W <= 0 || H <= 0) return;
     const int ntx = (W + TW - 1) / TW, nty = (H + TH - 1) / TH;
     const int nseg = H * ntx;
     hipLaunchKernelGGL(k_fast_planes, dim3(ntx, nty, F), dim3(256), 0, s, gray, W, H, T, seg, ntx);
     hipLaunchKernelGGL(k_seg_scan, dim3(F), dim3(1024), 0, s, seg, nseg, segoff, n_raw, raw_cap, status);
-    hipLaunchKernelGGL(k_fast_compact, dim3((nseg + 255) / 256, F), dim3(256), 0, s, seg, segoff, H, ntx, raw_xy,
-                       raw_score, raw_cap);
+    // the raster-order raw lists; the fused path's champion NMS bins straight from the planes and writes the
+    // list entries of the few points it keeps itself, so it skips this pass
+    if (compact)
+        hipLaunchKernelGGL(k_fast_compact, dim3((nseg + 255) / 256, F), dim3(256), 0, s, seg, segoff, H, ntx, raw_xy,
+                           raw_score, raw_cap);
 }

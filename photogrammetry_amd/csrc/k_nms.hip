@@ -92,6 +92,10 @@ struct NmsPtrs {
     uint2 *champ; // champion rounds: per cell {priority key of its best undecided point (0 = none), its xy}, padded grid
 };
 
+// champion rounds fill the raster-order raw lists (xy, score by raster rank) for the points they accept: the
+// descriptor stage looks the kept points up there, and the full lists are never needed (k_fast_compact is skipped)
+struct RawOut { uint32_t *xy; int32_t *score; };
+
 __device__ __forceinline__ NmsPtrs nms_ptrs(unsigned char *ws, const NmsLayout &L)
 {
     NmsPtrs p;
@@ -616,7 +620,8 @@ __global__ __launch_bounds__(256) void k_nms_champ(NmsLayout L, unsigned char *w
 // called by whole wavefronts: lane = one cell (c, valid when incell)
 template <int RR>
 __device__ __forceinline__ void phase_c_wave(const NmsPtrs &P, const NmsLayout &L, int radius, int round, int c, bool incell,
-                                             const uint32_t *cs, int cs_bias /* cell offsets: P.cell_start, 0 or an LDS slice */)
+                                             const uint32_t *cs, int cs_bias /* cell offsets: P.cell_start, 0 or an LDS slice */,
+                                             const RawOut &raw)
 {
     const int lane = threadIdx.x & 63;
     const int cc = incell ? c : 0;
@@ -701,8 +706,11 @@ __device__ __forceinline__ void phase_c_wave(const NmsPtrs &P, const NmsLayout &
         base = (uint32_t)__shfl((int)base, 0);
         if ((acc >> lane) & 1ull) {
             *rec_state(P.rec, P.cell_fill[c]) = ST_ACC_ROUND + (uint32_t)round; // the champion's record
-            P.sortkeys[base + (uint32_t)__popcll(acc & ((1ull << lane) - 1ull))] =
-                sort_key((int)(me.x >> 24) + 11, 0xFFFFFFu - (me.x & 0xFFFFFFu));
+            const int score = (int)(me.x >> 24) + 11;
+            const uint32_t rank = 0xFFFFFFu - (me.x & 0xFFFFFFu);
+            P.sortkeys[base + (uint32_t)__popcll(acc & ((1ull << lane) - 1ull))] = sort_key(score, rank);
+            raw.xy[rank] = me.y;
+            raw.score[rank] = score;
         }
     }
 }
@@ -714,14 +722,16 @@ constexpr int CS_LDS_MAX = 4096; // cell offsets a phase-C workgroup may stage (
 // rows +-R, a few KB: staged in LDS once, so that per centre the dependent global round trips are "records" only.
 // Pays only while a workgroup has dozens of centres (rounds 0 and 1); later rounds have few and skip it.
 template <int RR, bool STAGE>
-__global__ __launch_bounds__(256) void k_nms_phase_c(NmsLayout L, int radius, int round, unsigned char *ws_all,
-                                                     size_t ws_stride)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) // latency-bound: 8 waves/SIMD (<= 64 VGPRs) measured 6 % faster than 7
+void k_nms_phase_c(NmsLayout L, int radius, int round, unsigned char *ws_all,
+                                                     size_t ws_stride, uint32_t *raw_xy_all, int32_t *raw_score_all, int n_cap)
 {
     __shared__ uint32_t cs_lds[STAGE ? CS_LDS_MAX : 1];
     const int f = blockIdx.y;
     const int c0 = blockIdx.x * 256;
     const int c = c0 + threadIdx.x;
     const NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
+    const RawOut raw{raw_xy_all + (size_t)f * n_cap, raw_score_all + (size_t)f * n_cap};
     if (STAGE) {
         const int clast = c0 + 255 < L.ncell ? c0 + 255 : L.ncell - 1;
         int ylo = c0 / L.gw - RR, yhi = clast / L.gw + RR;
@@ -731,11 +741,11 @@ __global__ __launch_bounds__(256) void k_nms_phase_c(NmsLayout L, int radius, in
         if (n <= CS_LDS_MAX) {                                     // block-uniform
             for (int i = threadIdx.x; i < n; i += 256) cs_lds[i] = P.cell_start[lo + i];
             __syncthreads();
-            phase_c_wave<RR>(P, L, radius, round, c, c < L.ncell, cs_lds, lo); // separate call: the address space stays known
+            phase_c_wave<RR>(P, L, radius, round, c, c < L.ncell, cs_lds, lo, raw); // separate call: the address space stays known
             return;
         }
     }
-    phase_c_wave<RR>(P, L, radius, round, c, c < L.ncell, P.cell_start, 0);
+    phase_c_wave<RR>(P, L, radius, round, c, c < L.ncell, P.cell_start, 0, raw);
 }
 
 // Phase B, one wavefront per NEWLY accepted point (a few thousand per frame over all rounds): retire
@@ -819,11 +829,12 @@ __device__ __forceinline__ bool tail_suppressed(const NmsPtrs &P, const NmsLayou
     return false;
 }
 
-__global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw_score_all,
+__global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *raw_score_all,
                                                  const int32_t *__restrict__ n_raw_all, int n_cap, NmsLayout L,
                                                  int radius, unsigned char *ws_all, size_t ws_stride,
                                                  uint32_t *__restrict__ order_all, int32_t *__restrict__ n_kept_all,
-                                                 int kp_cap, int *status, int round0)
+                                                 int kp_cap, int *status, int round0, uint32_t *raw_xy_out,
+                                                 int32_t *raw_score_out)
 {
     extern __shared__ unsigned long long lds_keys[];
     __shared__ uint32_t wsum[NT / 64];
@@ -871,8 +882,9 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
                 const int i = base + tid;
                 const bool in = i < n_live;
                 const int c = in ? (int)cur[i] : 0;
-                if (L.R <= 2) phase_c_wave<2>(P, L, radius, round, c, in, P.cell_start, 0);
-                else phase_c_wave<3>(P, L, radius, round, c, in, P.cell_start, 0);
+                const RawOut raw{raw_xy_out + (size_t)f * n_cap, raw_score_out + (size_t)f * n_cap};
+                if (L.R <= 2) phase_c_wave<2>(P, L, radius, round, c, in, P.cell_start, 0, raw);
+                else phase_c_wave<3>(P, L, radius, round, c, in, P.cell_start, 0, raw);
             }
             __syncthreads();
             round++;
@@ -1041,11 +1053,13 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *__restrict__ raw
 
 size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap, bool planes) { return nms_layout(W, H, radius, n_cap, planes).total; }
 
+bool pgx_nms_fills_raw_lists(int W, int H, int radius, int n_cap) { return radius >= 0 && nms_layout(W, H, radius, n_cap, true).champ != 0; }
+
 namespace {
 
 struct NmsLaunch {
     hipStream_t s;
-    const uint32_t *raw_xy; const int32_t *raw_score; const int32_t *n_raw;
+    uint32_t *raw_xy; int32_t *raw_score; const int32_t *n_raw;
     int F, n_cap, W, H, radius;
     unsigned char *ws; size_t ws_stride;
     uint32_t *order; int32_t *n_kept; int kp_cap; int *status;
@@ -1083,11 +1097,11 @@ void nms_rounds(const NmsLaunch &a, int r0, int n)
         if (L.champ) {
             if (r > 0) hipLaunchKernelGGL(k_nms_champ, bgrid, dim3(256), 0, s, L, a.ws, a.ws_stride);
             if (L.R <= 2) {
-                if (r <= 1) hipLaunchKernelGGL((k_nms_phase_c<2, true>), bgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride);
-                else hipLaunchKernelGGL((k_nms_phase_c<2, false>), bgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride);
+                if (r <= 1) hipLaunchKernelGGL((k_nms_phase_c<2, true>), bgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride, a.raw_xy, a.raw_score, a.n_cap);
+                else hipLaunchKernelGGL((k_nms_phase_c<2, false>), bgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride, a.raw_xy, a.raw_score, a.n_cap);
             } else {
-                if (r <= 1) hipLaunchKernelGGL((k_nms_phase_c<3, true>), bgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride);
-                else hipLaunchKernelGGL((k_nms_phase_c<3, false>), bgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride);
+                if (r <= 1) hipLaunchKernelGGL((k_nms_phase_c<3, true>), bgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride, a.raw_xy, a.raw_score, a.n_cap);
+                else hipLaunchKernelGGL((k_nms_phase_c<3, false>), bgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride, a.raw_xy, a.raw_score, a.n_cap);
             }
         } else {
             hipLaunchKernelGGL(k_nms_phase_a, cgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride);
@@ -1105,10 +1119,10 @@ void nms_finish(const NmsLaunch &a, int round0)
         attr_set = true;
     }
     hipLaunchKernelGGL(k_nms_tail, dim3(a.F), dim3(NT), SORT_LDS_MAX * 8, a.s, a.raw_score, a.n_raw, a.n_cap, a.L, a.radius, a.ws,
-                       a.ws_stride, a.order, a.n_kept, a.kp_cap, a.status, round0);
+                       a.ws_stride, a.order, a.n_kept, a.kp_cap, a.status, round0, a.raw_xy, a.raw_score);
 }
 
-NmsLaunch nms_args(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw, int F, int n_cap,
+NmsLaunch nms_args(hipStream_t s, uint32_t *raw_xy, int32_t *raw_score, const int32_t *n_raw, int F, int n_cap,
                    int W, int H, int radius, void *wsv, size_t ws_stride, uint32_t *order, int32_t *n_kept, int kp_cap,
                    int *status, const unsigned long long *seg, const uint32_t *segoff)
 {
@@ -1131,7 +1145,7 @@ int wide_rounds_default()
 } // namespace
 
 // asynchronous form (fused detect path): a fixed number of whole-chip rounds, the tail kernel finishes
-void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw, int F,
+void pgx_launch_nms(hipStream_t s, uint32_t *raw_xy, int32_t *raw_score, const int32_t *n_raw, int F,
                     int n_cap, int W, int H, int radius, void *wsv, size_t ws_stride, uint32_t *order,
                     int32_t *n_kept, int kp_cap, int *status, const unsigned long long *seg, const uint32_t *segoff)
 {
@@ -1156,8 +1170,8 @@ hipError_t pgx_launch_nms_sync(hipStream_t s, const uint32_t *raw_xy, const int3
                                int n_cap, int W, int H, int radius, void *wsv, size_t ws_stride, uint32_t *order,
                                int32_t *n_kept, int kp_cap, int *status)
 {
-    const NmsLaunch a = nms_args(s, raw_xy, raw_score, n_raw, 1, n_cap, W, H, radius, wsv, ws_stride, order, n_kept, kp_cap,
-                                 status, nullptr, nullptr);
+    const NmsLaunch a = nms_args(s, const_cast<uint32_t *>(raw_xy), const_cast<int32_t *>(raw_score), n_raw, 1, n_cap, W, H, radius,
+                                 wsv, ws_stride, order, n_kept, kp_cap, status, nullptr, nullptr); // general path: lists are read only
     int r0 = 0;
     if (radius >= 0) {
         nms_setup(a);

@@ -90,7 +90,8 @@ int enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_
         ProfScope ps(c, "fast");
         pgx_launch_fast(c->stream, gray, F, W, H, c->threshold, c->ws_seg.as<unsigned long long>(),
                         c->ws_segoff.as<uint32_t>(), d_nraw, c->ws_rawxy.as<uint32_t>(),
-                        c->ws_rawscore.as<int32_t>(), raw_cap, c->d_status);
+                        c->ws_rawscore.as<int32_t>(), raw_cap, c->d_status,
+                        !pgx_nms_fills_raw_lists(W, H, c->radius, raw_cap));
     }
     {
         ProfScope ps(c, "nms");

@@ -146,11 +146,14 @@ size_t pgx_fast_seg_count(int W, int H);   // segments per frame
 void pgx_launch_fast(hipStream_t s, const float *gray, int F, int W, int H, float T,
                      unsigned long long *seg /*[F][nseg][4]*/, uint32_t *segoff /*[F][nseg]*/,
                      int32_t *n_raw /*[F]*/, uint32_t *raw_xy /*[F][raw_cap]*/,
-                     int32_t *raw_score /*[F][raw_cap]*/, int raw_cap, int *status);
+                     int32_t *raw_score /*[F][raw_cap]*/, int raw_cap, int *status,
+                     bool compact = true /* false: planes and ranks only, raw_xy/raw_score are not written */);
 
 // k_nms.hip
-size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap, bool planes);  // per frame; planes: the fused detect path
-void pgx_launch_nms(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw,
+size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap, bool planes);
+// true when pgx_launch_nms with planes never reads raw_xy/raw_score and fills in the kept points' entries itself
+bool pgx_nms_fills_raw_lists(int W, int H, int radius, int n_cap);  // per frame; planes: the fused detect path
+void pgx_launch_nms(hipStream_t s, uint32_t *raw_xy, int32_t *raw_score, const int32_t *n_raw,
                     int F, int n_cap, int W, int H, int radius, void *ws, size_t ws_stride,
                     uint32_t *order /*[F][kp_cap]*/, int32_t *n_kept /*[F]*/, int kp_cap, int *status,
                     const unsigned long long *seg = nullptr /* FAST planes: enables atomic-free binning */,
