@@ -15,8 +15,8 @@
 //                   Pass 2, one lane per QUEUED pixel (all lanes busy): the rest of the ring and the
 //                   run-length rule; score bits are OR-ed into the tile's three ballot planes in LDS.
 //                   Per 64-pixel row segment: three 64-bit planes + the count -> seg[F][H][ntx][4]
-//   k_seg_scan      one workgroup per frame: exclusive scan of the counts in (y, tx) order
-//                   = raster order; n_raw[f]
+//   k_seg_scan      one workgroup per frame: exclusive scan (in place) of the dense per-segment counts that
+//                   k_fast_planes also writes, in (y, tx) order = raster order; n_raw[f]
 //   k_fast_compact  one thread per segment walks its set bits in x order -> raw_xy/raw_score
 #include "pgx_internal.h"
 
@@ -27,7 +27,8 @@ constexpr int LROWS = TH + 2 * HALO;  // 38
 constexpr int LSTRIDE = 72;           // >= 70, keeps rows 16-B aligned
 
 __global__ __launch_bounds__(256) void k_fast_planes(const float *__restrict__ gray, int W, int H, float T,
-                                                     unsigned long long *__restrict__ seg, int ntx)
+                                                     unsigned long long *__restrict__ seg, int ntx,
+                                                     uint32_t *__restrict__ segcnt)
 {
     __shared__ float tile[LROWS][LSTRIDE];
     __shared__ uint16_t queue[TW * TH];  // pixels that passed the compass test: row << 10 | column << 4 | compass bits
@@ -157,21 +158,21 @@ __global__ __launch_bounds__(256) void k_fast_planes(const float *__restrict__ g
             const unsigned long long b2 = planes[ry][2][0] | ((unsigned long long)planes[ry][2][1] << 32);
             unsigned long long *o = seg + (((size_t)f * H + y) * ntx + tx) * 4;
             *reinterpret_cast<ulonglong2 *>(o) = make_ulonglong2(b0, b1);
-            *reinterpret_cast<ulonglong2 *>(o + 2) = make_ulonglong2(b2, (unsigned long long)__popcll(b0 | b1 | b2));
+            const uint32_t cnt = (uint32_t)__popcll(b0 | b1 | b2);
+            *reinterpret_cast<ulonglong2 *>(o + 2) = make_ulonglong2(b2, (unsigned long long)cnt);
+            segcnt[((size_t)f * H + y) * ntx + tx] = cnt; // dense copy of the counts: k_seg_scan turns it into offsets in place
         }
     }
 }
 
 // exclusive scan of per-segment counts, one 1024-thread workgroup per frame
-__global__ __launch_bounds__(1024) void k_seg_scan(const unsigned long long *__restrict__ seg, int nseg,
-                                                   uint32_t *__restrict__ segoff, int32_t *__restrict__ n_raw,
+__global__ __launch_bounds__(1024) void k_seg_scan(int nseg, uint32_t *__restrict__ segoff, int32_t *__restrict__ n_raw,
                                                    int raw_cap, int *status)
 {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
     const int f = blockIdx.x;
-    const unsigned long long *sg = seg + (size_t)f * nseg * 4;
-    uint32_t *so = segoff + (size_t)f * nseg;
+    uint32_t *so = segoff + (size_t)f * nseg; // in: counts (written by k_fast_planes), out: exclusive offsets
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
@@ -179,8 +180,13 @@ __global__ __launch_bounds__(1024) void k_seg_scan(const unsigned long long *__r
         // each thread owns 4 consecutive segments
         const int i0 = base + tid * 4;
         uint32_t c[4];
+        if (i0 + 3 < nseg && (nseg & 3) == 0) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(so + i0);
+            c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) c[k] = (i0 + k < nseg) ? (uint32_t)sg[(size_t)(i0 + k) * 4 + 3] : 0u;
+            for (int k = 0; k < 4; k++) c[k] = (i0 + k < nseg) ? so[i0 + k] : 0u;
+        }
         uint32_t tsum = c[0] + c[1] + c[2] + c[3];
         uint32_t incl = tsum;
 #pragma unroll
@@ -248,8 +254,8 @@ void pgx_launch_fast(hipStream_t s, const float *gray, int F, int W, int H, floa
     if (F <= 0 || W <= 0 || H <= 0) return;
     const int ntx = (W + TW - 1) / TW, nty = (H + TH - 1) / TH;
     const int nseg = H * ntx;
-    hipLaunchKernelGGL(k_fast_planes, dim3(ntx, nty, F), dim3(256), 0, s, gray, W, H, T, seg, ntx);
-    hipLaunchKernelGGL(k_seg_scan, dim3(F), dim3(1024), 0, s, seg, nseg, segoff, n_raw, raw_cap, status);
+    hipLaunchKernelGGL(k_fast_planes, dim3(ntx, nty, F), dim3(256), 0, s, gray, W, H, T, seg, ntx, segoff);
+    hipLaunchKernelGGL(k_seg_scan, dim3(F), dim3(1024), 0, s, nseg, segoff, n_raw, raw_cap, status);
     // the raster-order raw lists; the fused path's champion NMS bins straight from the planes and writes the
     // list entries of the few points it keeps itself, so it skips this pass
     if (compact)
