@@ -274,8 +274,10 @@ def main():
             rooflines["dewarp_gray"] = hbm("dewarp_gray", per_px * npix * F,
                                            "%.0f B/pixel/frame (8 gathered source + 4 grey + 8 map per 4 frames) x %d px x %d frames per launch" % (per_px, npix, F))
         if "fast" in kern:
-            rooflines["fast"] = hbm("fast", 4.5 * npix * F + 16.0 * n_raw_tot,
-                                    "4 B/px grey read + 0.5 B/px ballot planes + 16 B per raw hit, %d frames (3 launches)" % F)
+            nseg = H * ((W + 63) // 64)
+            rooflines["fast"] = hbm("fast", (4.5 * npix + 8.0 * nseg) * F,
+                                    "4 B/px grey read + 0.5 B/px ballot planes + 8 B per 64-px row segment (count, then raster "
+                                    "offset), %d frames (2 launches; the raw lists are not materialised on this path)" % F)
         if "nms" in kern:
             rooflines["nms"] = hbm("nms", 8.0 * n_raw_tot + 4.0 * n_kept_tot,
                                    "integer/latency-bound stage on L2-resident lists: 8 B per raw hit in + 4 B per survivor out "
