@@ -8,7 +8,8 @@
 // (score desc, input index asc).  Round: every undecided point with no higher-priority
 // undecided point within r is accepted (phase A); every undecided point within r of an accepted
 // one is suppressed (phase B).  Output = accepted points in priority order.  On a 1080p frame with
-// 1e5 raw hits the undecided set shrinks ~2.6x per round (9 rounds).
+// 1e5 raw hits and r = 16 the undecided set roughly halves per round (about ten rounds); larger radii on dense
+// hits form long dependency chains and need dozens.
 //
 // Two launch structures (all frames of a batch in every launch, blockIdx.y = frame).  The fused detect path
 // with 10 <= r <= 192 uses the CHAMPION ROUNDS described further down (k_nms_bin_planes, k_nms_champ,
