@@ -251,3 +251,46 @@ def test_detect_dense_noise_frame_vs_oracle(engine, radius):
     kp = d_kp.cpu().numpy()[0]
     assert (kp[:n, 0] == kept["x"]).all() and (kp[:n, 1] == kept["y"]).all() and (kp[:n, 2] == kept["fast_score"]).all()
     assert (d_desc.cpu().numpy().view(np.uint32)[0, :n] == edesc).all()
+
+
+def test_two_contexts_in_flight_are_independent():
+    """Two contexts (two HIP streams) with different parameters enqueue detect + match back to back without any
+    synchronisation in between; both results must equal the oracle (contexts share nothing but the device)."""
+    W, H, CAP = 640, 360, 4096
+    T = np.float32(0.1)
+    frames = np.stack([synth.make_frame(W, H, seed=21 + i, n_shapes=900) for i in range(4)])
+    cfg = [dict(radius=16, pairs=pg.make_brief_pairs(5, 50, 256)), dict(radius=11, pairs=pg.make_brief_pairs(6, 30, 256))]
+    engs, outs = [], []
+    d_frames = torch.from_numpy(frames).to(DEV)
+    pl = torch.tensor([[0, 1], [2, 3], [3, 0]], dtype=torch.int32, device=DEV)
+    for c in cfg:
+        e = pg.Engine(0)
+        e.set_brief_pairs(c["pairs"])
+        e.set_detect_params(T, c["radius"])
+        e.set_capacity(1 << 17, CAP)
+        e.set_dewarp_map(None)
+        engs.append(e)
+        outs.append(dict(kp=torch.zeros((4, CAP, 4), dtype=torch.int32, device=DEV),
+                         desc=torch.zeros((4, CAP, 8), dtype=torch.int32, device=DEV),
+                         counts=torch.zeros(4, dtype=torch.int32, device=DEV),
+                         nraw=torch.zeros(4, dtype=torch.int32, device=DEV),
+                         out=torch.zeros((3, CAP, 3), dtype=torch.int32, device=DEV)))
+    for _ in range(3):   # several rounds in flight on both streams
+        for e, o in zip(engs, outs):
+            e.detect_batch_dev(d_frames, 4, W, H, o["kp"], o["desc"], o["counts"], o["nraw"], CAP)
+            e.match_batch_dev(o["desc"], o["counts"], CAP, 8, pl, 3, o["out"])
+    for e in engs:
+        e.check_status()
+    for c, o in zip(cfg, outs):
+        counts = o["counts"].cpu().numpy()
+        desc = o["desc"].cpu().numpy().view(np.uint32)
+        res = o["out"].cpu().numpy()
+        exp = [_oracle_detect(frames[f], None, c["pairs"], T, c["radius"], CAP) for f in range(4)]
+        for f in range(4):
+            assert counts[f] == len(exp[f][0]) and (desc[f, :counts[f]] == exp[f][1]).all()
+        for m, (a, b) in enumerate([(0, 1), (2, 3), (3, 0)]):
+            em = cref.match_sorted(exp[a][1], exp[b][1])
+            got = res[m][:counts[a]]
+            assert (got[:, 0] == em["k1"]).all() and (got[:, 1] == em["k2"]).all() and (got[:, 2] == em["dist"]).all()
+    for e in engs:
+        e.close()
