@@ -644,37 +644,42 @@ static void launch_finish(hipStream_t s, uint32_t *ws, const uint32_t *desc, con
                        plan.stride, plan.words, out, (uint32_t)key_cap, tail_in_lds, status);
 }
 
-void pgx_launch_match(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_counts,
-                      const int32_t *d_pairlist, const MatchPlan &plan, void *wsv, pgx_pair *d_out, int *status)
+void pgx_launch_match_wide(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_counts,
+                           const int32_t *d_pairlist, const MatchPlan &plan, void *wsv, int *status)
 {
     if (plan.M <= 0) return;
     uint32_t *ws = reinterpret_cast<uint32_t *>(wsv);
     {
-        ProfScope ps(ctx, "match_init");
+        ProfScope ps(ctx, "match_init", s);
         hipLaunchKernelGGL(k_match_init, dim3((plan.stride + 255) / 256 > 64 ? 64 : (plan.stride + 255) / 256, plan.M),
                            dim3(256), 0, s, ws, d_counts, d_pairlist, plan.stride, plan.max_n, status);
     }
     const bool mfma_ok = (plan.words == 8) && pgx_mfma_enabled();
     for (int r = 0; r < plan.rounds_mfma; r++) {
         {
-            ProfScope ps(ctx, "ham_argmin");
+            ProfScope ps(ctx, "ham_argmin", s);
             if (mfma_ok) pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan);
             else if (plan.words == 8) launch_rounds_valu<8>(s, ws, d_desc, d_pairlist, plan);
             else launch_rounds_valu<0>(s, ws, d_desc, d_pairlist, plan);
         }
         {
-            ProfScope ps(ctx, "match_select");
+            ProfScope ps(ctx, "match_select", s);
             hipLaunchKernelGGL(k_match_select, dim3(plan.M), dim3(SEL_NT), 0, s, ws, plan.stride,
                                reinterpret_cast<unsigned long long *>(status + 4) + (r < PGX_MAX_WIDE_ROUNDS ? r : PGX_MAX_WIDE_ROUNDS - 1));
         }
     }
     if (plan.words == 8) {
-        ProfScope ps(ctx, "tail_fill");
+        ProfScope ps(ctx, "tail_fill", s);
         hipLaunchKernelGGL(k_tail_fill, dim3(PGX_TAIL_MAX / 16, 2, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
     }
-    {
-        ProfScope ps(ctx, "match_finish");
-        if (plan.words == 8) launch_finish<8>(s, ws, d_desc, d_pairlist, plan, d_out, status);
-        else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out, status);
-    }
+}
+
+void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_pairlist,
+                             const MatchPlan &plan, void *wsv, pgx_pair *d_out, int *status)
+{
+    if (plan.M <= 0) return;
+    uint32_t *ws = reinterpret_cast<uint32_t *>(wsv);
+    ProfScope ps(ctx, "match_finish", s);
+    if (plan.words == 8) launch_finish<8>(s, ws, d_desc, d_pairlist, plan, d_out, status);
+    else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out, status);
 }

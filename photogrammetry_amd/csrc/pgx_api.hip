@@ -128,10 +128,42 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     for (int n = plan.max_n; n > PGX_TAIL_FILL_MAX && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
     if (plan.rounds_mfma > 0 && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS) plan.rounds_mfma++;
     HIPCHK(c, hipMemsetAsync(c->d_status + 4, 0, PGX_MAX_WIDE_ROUNDS * 8, c->stream));
-    for (int m0 = 0; m0 < M; m0 += CHUNK) {
-        plan.M = (M - m0 < CHUNK) ? M - m0 : CHUNK;
-        pgx_launch_match(c, c->stream, d_desc, d_counts, d_pairlist + 2 * (size_t)m0, plan, c->ws_match.p,
-                         d_out + (size_t)m0 * stride, c->d_status);
+    if (M <= CHUNK) { // one chunk: everything in order on the context's stream
+        plan.M = M;
+        pgx_launch_match_wide(c, c->stream, d_desc, d_counts, d_pairlist, plan, c->ws_match.p, c->d_status);
+        pgx_launch_match_finish(c, c->stream, d_desc, d_pairlist, plan, c->ws_match.p, d_out, c->d_status);
+    } else {
+        // Several chunks: the per-pair finish is a latency-bound chain on one workgroup per image pair (a quarter of
+        // the chip at 128 pairs), so the finish of chunk i runs on a second stream beside the whole-chip rounds of
+        // chunk i + 1.  Two workspaces alternate; events order "inputs ready -> wide(i) -> finish(i) -> wide(i + 2)".
+        HIPCHK(c, c->ws_match2.ensure(pgx_match_ws_bytes(mc, stride)));
+        for (int k = 0; k < 2; k++) {
+            if (!c->mstream[k]) HIPCHK(c, hipStreamCreateWithFlags(&c->mstream[k], hipStreamNonBlocking));
+            if (!c->ev_wide[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_wide[k], hipEventDisableTiming));
+            if (!c->ev_fin[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fin[k], hipEventDisableTiming));
+            if (!c->ev_join[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
+        }
+        if (!c->ev_in) HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+        hipStream_t sw = c->mstream[0], sf = c->mstream[1];
+        HIPCHK(c, hipEventRecord(c->ev_in, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(sw, c->ev_in, 0));
+        HIPCHK(c, hipStreamWaitEvent(sf, c->ev_in, 0));
+        int i = 0;
+        for (int m0 = 0; m0 < M; m0 += CHUNK, i++) {
+            const int b = i & 1;
+            void *ws = b ? c->ws_match2.p : c->ws_match.p;
+            plan.M = (M - m0 < CHUNK) ? M - m0 : CHUNK;
+            if (i >= 2) HIPCHK(c, hipStreamWaitEvent(sw, c->ev_fin[b], 0)); // this workspace's previous chunk is finished
+            pgx_launch_match_wide(c, sw, d_desc, d_counts, d_pairlist + 2 * (size_t)m0, plan, ws, c->d_status);
+            HIPCHK(c, hipEventRecord(c->ev_wide[b], sw));
+            HIPCHK(c, hipStreamWaitEvent(sf, c->ev_wide[b], 0));
+            pgx_launch_match_finish(c, sf, d_desc, d_pairlist + 2 * (size_t)m0, plan, ws, d_out + (size_t)m0 * stride, c->d_status);
+            HIPCHK(c, hipEventRecord(c->ev_fin[b], sf));
+        }
+        HIPCHK(c, hipEventRecord(c->ev_join[0], sw));
+        HIPCHK(c, hipEventRecord(c->ev_join[1], sf));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[0], 0));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[1], 0));
     }
     c->last_rounds_mfma = plan.rounds_mfma;
     HIPCHK(c, hipGetLastError());
@@ -181,10 +213,17 @@ void pgx_ctx_destroy(pgx_ctx *c)
         for (auto &ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     DevBuf *bufs[] = {&c->d_pairs, &c->d_map, &c->ws_gray, &c->ws_seg, &c->ws_segoff, &c->ws_nraw, &c->ws_rawxy,
                       &c->ws_rawscore, &c->ws_nms, &c->ws_order, &c->ws_nkept, &c->st_a, &c->st_b, &c->st_c,
-                      &c->st_d, &c->st_e, &c->st_f, &c->ws_match};
+                      &c->st_d, &c->st_e, &c->st_f, &c->ws_match, &c->ws_match2};
     for (DevBuf *b : bufs) b->release();
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
+    for (int k = 0; k < 2; k++) {
+        if (c->mstream[k]) (void)hipStreamDestroy(c->mstream[k]);
+        if (c->ev_wide[k]) (void)hipEventDestroy(c->ev_wide[k]);
+        if (c->ev_fin[k]) (void)hipEventDestroy(c->ev_fin[k]);
+        if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
+    }
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

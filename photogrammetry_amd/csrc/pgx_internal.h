@@ -80,8 +80,11 @@ struct pgx_ctx {
     DevBuf ws_gray, ws_seg, ws_segoff, ws_nraw, ws_rawxy, ws_rawscore, ws_nms, ws_order, ws_nkept;
     // host-API staging
     DevBuf st_a, st_b, st_c, st_d, st_e, st_f;
-    // match workspaces
-    DevBuf ws_match;
+    // match workspaces: two, so that with more than one chunk of image pairs the per-pair finish of chunk i runs
+    // (on its own stream) beside the wide rounds of chunk i + 1
+    DevBuf ws_match, ws_match2;
+    hipStream_t mstream[2] = {nullptr, nullptr}; // [0] wide rounds, [1] finishes (created on first use)
+    hipEvent_t ev_in = nullptr, ev_wide[2] = {nullptr, nullptr}, ev_fin[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
 
     // profiling
     bool prof_on = false;
@@ -117,17 +120,18 @@ struct ProfScope {
     pgx_ctx *c;
     ProfEntry *e = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(pgx_ctx *ctx, const char *name) : c(ctx)
+    hipStream_t st;
+    ProfScope(pgx_ctx *ctx, const char *name, hipStream_t s = nullptr) : c(ctx), st(s ? s : ctx->stream)
     {
         if (!c->prof_on) return;
         e = &c->prof[name];
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { e = nullptr; return; }
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, st);
     }
     ~ProfScope()
     {
         if (!e) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, st);
         e->pending.emplace_back(a, b);
     }
 };
@@ -182,5 +186,9 @@ struct MatchPlan {
     int rounds_mfma;
 };
 size_t pgx_match_ws_bytes(int M, int stride);
-void pgx_launch_match(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_counts,
-                      const int32_t *d_pairlist, const MatchPlan &plan, void *ws, pgx_pair *d_out, int *status);
+// wide part (init, whole-chip rounds, tail fill) and per-pair finish of one chunk of image pairs; they may run on
+// different streams (the caller orders them with an event)
+void pgx_launch_match_wide(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_counts,
+                           const int32_t *d_pairlist, const MatchPlan &plan, void *ws, int *status);
+void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_pairlist,
+                             const MatchPlan &plan, void *ws, pgx_pair *d_out, int *status);
