@@ -379,7 +379,8 @@ def test_star_pair_end_to_end(engine, star):
     engine.set_dewarp_map(None)
 
 
-@pytest.mark.parametrize("W,H,radius,with_map", [(320, 200, 8, True), (640, 360, 20, False), (451, 383, 50, True)])
+@pytest.mark.parametrize("W,H,radius,with_map", [(320, 200, 8, True), (640, 360, 20, False), (451, 383, 50, True),
+                                                 (451, 383, 16, False), (333, 77, 12, True), (70, 66, 10, False)])
 def test_detect_synthetic_vs_oracle(engine, W, H, radius, with_map):
     """Fused dewarp->gray->FAST->NMS->BRIEF on a synthetic corner-rich frame vs the oracle chain."""
     frame = synth.make_frame(W, H, seed=W + H)
