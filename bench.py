@@ -1,32 +1,44 @@
 #!/usr/bin/env python3
 """bench.py -- descriptor pairs matched per second on MI355X (BASELINE.json's metric).
 
-Workload (BASELINE.json configs[1]): 1920x1080 RGBA64 frame pairs, dewarp -> gray -> FAST-like
-detect -> NMS (r=16) -> BRIEF-256 -> all-pairs Hamming match with the reference's greedy
-assignment, 4096 keypoints per frame (lists truncated to their first 4096 in NMS order: a harness
-choice, the reference has no cap).  One "step" = one batch of B independent image pairs per GPU
-(--pairs-per-step, default 64), frames already resident in HBM; value = sum over pairs of N1*N2
-divided by the WHOLE step time (detect + match), max over ranks.  Weak scaling: every rank
-processes its own B pairs; the per-pair match lists are all-gathered (RCCL) once after the timed
-region's last step -- they are the input of the (host-side) track graph.
+    python bench.py --gpus N --steps K --warmup W
+
+Headline workload (BASELINE configs[2] = SURVEY 8d config 3, the batched form of configs[1]): a 64-frame
+1920x1080 RGBA64 sequence (frame_i = frame_0 translated by (3i, i) px), every frame through
+dewarp -> gray -> FAST-like detect -> NMS (r = 16) -> BRIEF-256, then ALL ordered image pairs i < j (2016) through
+the all-pairs Hamming distance + the reference's greedy assignment, <= 4096 keypoints per frame (lists cut to
+their first 4096 in NMS order: a harness choice, the reference has no cap).  One "step" = one such job, frames
+resident in HBM when the timed region starts; value = sum over image pairs of N1*N2 / whole step time
+(detect + exchange + match + exchange), max over ranks.
+
+N GPUs: one process per GPU.  `python bench.py --gpus N` is itself the launcher: the parent spawns N children
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE anything touches a GPU -- it imports
+neither torch nor the pgx library -- forwards rank 0's JSON line and exits non-zero if any child fails.  Under
+`python -m torch.distributed.run ... bench.py --gpus N` the ranks already exist and --gpus must equal WORLD_SIZE.
+Every step runs photogrammetry_amd.dist.ShardedSequence's four phases on the GPU: frames f mod N ->
+pgx_detect_batch_dev -> RCCL all-gather of {count, descriptors} -> image pairs p mod N -> pgx_match_batch_dev ->
+RCCL all-gather of the match lists.  N = 1 runs the same code with the collectives elided.
+--scaling weak (default): the job is N independent 64-frame sequences (64 frames and 2016 image pairs per GPU,
+frames and pairs of all sequences dealt round-robin over the ranks, so both exchanges are real);
+--scaling strong: one sequence whatever N.
 
 Extra objects on the JSON line:
-  roofline     the dominant kernel of the step by measured time (HIP events around its launches,
-               recorded on the launch stream during the timed steps)
-  kernels      per-kernel-group launches / avg ms over the timed region
-  match_only   pairs/s of the match stage alone (SURVEY 8d's definition of the metric)
-  overlap      the same K steps timed again with --overlap-streams contexts in flight (informative:
-               `value` is always the single-stream figure unless --streams says otherwise)
-  cpu_baseline the CPU oracle (literal single-thread port of the C#) timed on a bounded sample; beside it the
-               optimised matcher on one core and on --cpu-procs processes (N = 1 only)
+  roofline      the dominant kernel of the step by measured time (HIP events on the launch stream, timed steps)
+  mfma          the metric's kernel (k_ham_mfma): achieved int8 op/s against the dense int8 MFMA peak
+  rooflines / kernels   every kernel group; traffic = HBM bytes from separate rocprofv3 --pmc passes (profiles/)
+  match_only    pairs/s of the match stage alone (SURVEY 8d's definition of the metric)
+  configs       (N = 1) the other BASELINE configurations on this GPU: configs[1] x 64 independent pairs,
+                configs[3]'s one-GPU window variant (1024 x 3840x2160, 0 < j - i <= 16, 8192 keypoints)
+  host_api      (N = 1) pgx_detect / pgx_match from HOST buffers (what a P/Invoke caller sees), PCIe included
+  cpu_baseline  (N = 1) the CPU oracle (literal single-thread port of the C#) on a bounded sample; beside it the
+                optimised matcher on one core and on --cpu-procs processes, CPU model and core counts stated
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -37,53 +49,125 @@ WORDS = 8
 NKP = 4096
 RADIUS = 16
 THRESH = 0.1
-I8_MFMA_PEAK_OPS = 5.0e15   # dense int8 MFMA, /opt/skills/guides/MI355X_MICROARCH.md (2x bf16 2.5 PF)
-VALU_PEAK_LANEOPS = 256 * 128 * 2.4e9
+SEQ_FRAMES = 64
+I8_MFMA_PEAK_OPS = 5.0e15   # dense int8 MFMA, /opt/skills/guides/MI355X_MICROARCH.md (2x the 2.5 PF bf16 figure)
 HBM_PEAK = 8.0e12
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_inputs(pairs_per_step, rank, cache_dir="/tmp/pgx_bench_cache"):
-    """2B frames: pair p = (base frame p mod NB, the same frame translated by a pair-specific offset), NB = min(B, 8)
-    seeded base frames per rank.  Every frame of the batch is a different image."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--frames", type=int, default=SEQ_FRAMES, help="frames per sequence (all ordered pairs are matched)")
+    ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-procs", type=int, default=16,
+                    help="processes of the multi-core CPU bar (0/1 = skip); 16 = a one-GPU box's CPU share")
+    ap.add_argument("--no-dewarp", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs / host_api objects (N = 1)")
+    ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
+    ap.add_argument("--master-port", type=int, default=0)
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------
+# launcher: runs in a process that never touches the GPU
+# ---------------------------------------------------------------------------------------------------
+
+def spawn_ranks(args, argv):
+    """Start args.gpus copies of this script, one per GPU, and relay rank 0's JSON line.  Nothing in this
+    process imports torch or loads libpgx: the children are created before any GPU call exists anywhere."""
+    import socket
+    assert "torch" not in sys.modules and "photogrammetry_amd" not in sys.modules
+    port = args.master_port
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "PGX_BENCH_CHILD": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        log("bench.py: ranks failed (rank, exit code): %s" % bad)
+        return 1
+    if not any(line.startswith("{") for line in out0.splitlines()):
+        log("bench.py: rank 0 printed no JSON line")
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# inputs (made on the device from seeded host-made base frames)
+# ---------------------------------------------------------------------------------------------------
+
+def base_frame(w, h, seed, cache_dir="/tmp/pgx_bench_cache"):
+    import numpy as np
     from photogrammetry_amd import synth
     os.makedirs(cache_dir, exist_ok=True)
-    nb = min(pairs_per_step, 8)
-    bases = []
-    for b in range(nb):
-        seed = 1234 + 1000 * rank + b
-        path = os.path.join(cache_dir, "frame_%dx%d_%d.npy" % (W, H, seed))
-        f0 = None
-        if os.path.exists(path):
-            try:
-                f0 = np.load(path)
-                if f0.shape != (H, W, 4) or f0.dtype != np.uint16:
-                    f0 = None
-            except (OSError, ValueError):
-                f0 = None   # a torn file from an interrupted run: regenerate
-        if f0 is None:
-            f0 = synth.make_frame(W, H, seed=seed, n_shapes=20000)
-            try:
-                tmp = "%s.%d.tmp.npy" % (path, os.getpid())
-                np.save(tmp, f0)
-                os.replace(tmp, path)   # atomic: another rank or run never sees a partial file
-            except OSError:
-                pass
-        bases.append(f0)
-    frames = []
-    for p in range(pairs_per_step):
-        k = p // nb
-        base = bases[p % nb] if k == 0 else synth.shift_frame(bases[p % nb], -13 * k, 7 * k)
-        frames.append(base)
-        frames.append(synth.shift_frame(base, 37 + 5 * k, 11 + 3 * k))
-    return np.stack(frames)  # [2B][H][W][4]
+    path = os.path.join(cache_dir, "frame_%dx%d_%d.npy" % (w, h, seed))
+    if os.path.exists(path):
+        try:
+            f0 = np.load(path)
+            if f0.shape == (h, w, 4) and f0.dtype == np.uint16:
+                return f0
+        except (OSError, ValueError):
+            pass   # a torn file from an interrupted run: regenerate
+    f0 = synth.make_frame(w, h, seed=seed, n_shapes=int(20000 * (w * h) / (1920 * 1080)))
+    try:
+        tmp = "%s.%d.tmp.npy" % (path, os.getpid())
+        np.save(tmp, f0)
+        os.replace(tmp, path)   # atomic: another rank or run never sees a partial file
+    except OSError:
+        pass
+    return f0
 
+
+def roll_frames(torch, d_base, shifts, out=None):
+    """Wrap-around translations of one device-resident RGBA64 base frame (one pixel = one int64: roll has no uint16)."""
+    h, w = d_base.shape[:2]
+    if out is None:
+        out = torch.empty((len(shifts), h, w, 4), dtype=torch.uint16, device=d_base.device)
+    b64, o64 = d_base.view(torch.int64), out.view(torch.int64)
+    for k, (dx, dy) in enumerate(shifts):
+        o64[k] = torch.roll(b64, shifts=(dy % h, dx % w), dims=(0, 1))
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): the oracle as the checker's clock, never in the product path
+# ---------------------------------------------------------------------------------------------------
 
 def _cpu_pair_worker(path):
     """One process of the multi-core CPU bar: the oracle's optimised single-thread pipeline on the sample pair."""
+    import numpy as np
     from oracle import cref
     z = np.load(path)
     t0 = time.time()
@@ -102,6 +186,7 @@ def cpu_multicore(frames, dmap, pairs, nproc):
     import concurrent.futures
     import multiprocessing
     import tempfile
+    import numpy as np
     d = tempfile.mkdtemp(prefix="pgx_cpu_")
     path = os.path.join(d, "pair0.npz")
     np.savez(path, f0=frames[0], f1=frames[1], dmap=dmap, pairs=pairs)
@@ -137,7 +222,8 @@ def cpu_multicore(frames, dmap, pairs, nproc):
 
 def cpu_baseline(frames, dmap, pairs, sample_n):
     """The oracle (literal C port, 1 thread) on a bounded sample of the same workload:
-    detect chain on the two frames of pair 0, literal Theta(N^3) match on the first sample_n keypoints."""
+    detect chain on the first two frames of the sequence, literal Theta(N^3) match on their first sample_n keypoints."""
+    import numpy as np
     from oracle import cref
     t0 = time.time()
     descs = []
@@ -158,252 +244,394 @@ def cpu_baseline(frames, dmap, pairs, sample_n):
             "optimised": {"value": n1 * n2 / (t_detect + t_sorted), "match_s": t_sorted,
                           "what": "same sample, matcher replaced by the oracle's sort-all-edges-then-scan greedy "
                                   "(hardware popcount, 1 thread): the fair single-core CPU bar of SURVEY 8d"},
-            "sample": "pair 0 of the workload: dewarp+gray+detect+NMS+BRIEF of both 1920x1080 frames (%.2f s) + literal "
+            "sample": "frames 0 and 1 of the sequence: dewarp+gray+detect+NMS+BRIEF of both 1920x1080 frames (%.2f s) + literal "
                       "Theta(N^3) greedy match of the first %dx%d keypoints (%.2f s); C restatement of the C# "
                       "(hardware popcount, so faster than the real BigInteger loop)" % (t_detect, n1, n2, t_match),
             "detect_s_per_frame": t_detect / 2, "match_s": t_match, "match_n": [n1, n2]}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-step", type=int, default=64)
-    ap.add_argument("--cpu-sample", type=int, default=4096)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-procs", type=int, default=16, help="processes of the multi-core CPU bar (0/1 = skip)")
-    ap.add_argument("--no-dewarp", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, help="steps kept in flight (one pgx context + HIP stream each)")
-    ap.add_argument("--overlap-streams", type=int, default=2,
-                    help="after the timed region, time the same K steps again with this many contexts/streams in flight "
-                         "and report it as `overlap` (0 = skip); `value` always comes from --streams")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------
 
+KERNEL_GROUPS = ("dewarp_gray", "fast", "nms", "brief", "match_init", "ham_argmin", "match_select", "tail_fill", "match_finish")
+
+
+def kernel_table(eng, steps):
+    kern = {}
+    for name in KERNEL_GROUPS:
+        n, ms = eng.profile_get(name)
+        if n:
+            kern[name] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / steps}
+    return kern
+
+
+def worker(args):
+    import numpy as np
     import torch
     import torch.distributed as dist
     import photogrammetry_amd as pg
+    from photogrammetry_amd import dist as pdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        log("bench.py: --gpus %d but WORLD_SIZE is %d: refusing to report a run on a different number of GPUs" % (args.gpus, world))
+        return 2
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        log("bench.py: rank %d needs GPU %d but only %d visible: --gpus %d cannot run here" % (rank, local_rank, ndev, world))
+        return 3
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    B = args.pairs_per_step
-    F = 2 * B
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     t_setup = time.time()
-    frames_h = make_inputs(B, rank)
+    nseq = world if args.scaling == "weak" else 1
+    FS = args.frames
+    n_frames = nseq * FS
+    pair_list = [(s * FS + i, s * FS + j) for s in range(nseq) for i in range(FS) for j in range(i + 1, FS)]
     pairs = pg.make_brief_pairs(0, 50, P)
     dmap = None if args.no_dewarp else pg.build_dewarp_map(W, H, [3e-4, 1e-7, 0, 0, 0])
-    NS = max(1, args.streams)
-    NO = max(0, args.overlap_streams)
-    CAP = 8192
-    d_frames = torch.from_numpy(frames_h).to(dev)
-    pairlist = torch.tensor([[2 * p, 2 * p + 1] for p in range(B)], dtype=torch.int32, device=dev)
-    engs, bufs = [], []
-    for _ in range(max(NS, NO)):
-        e = pg.Engine(local_rank)          # own non-blocking HIP stream per context
-        e.set_brief_pairs(pairs)
-        e.set_detect_params(THRESH, RADIUS)
-        e.set_capacity(1 << 18, 8192)
-        e.set_dewarp_map(dmap)
-        engs.append(e)
-        bufs.append(dict(kp=torch.zeros((F, CAP, 4), dtype=torch.int32, device=dev),
-                         desc=torch.zeros((F, CAP, WORDS), dtype=torch.int32, device=dev),
-                         counts=torch.zeros(F, dtype=torch.int32, device=dev),
-                         nraw=torch.zeros(F, dtype=torch.int32, device=dev),
-                         out=torch.zeros((B, CAP, 3), dtype=torch.int32, device=dev)))
-    eng = engs[0]
-    d_counts, d_nraw, d_out = bufs[0]["counts"], bufs[0]["nraw"], bufs[0]["out"]
+    eng = pg.Engine(local_rank)
+    eng.set_brief_pairs(pairs)
+    eng.set_detect_params(THRESH, RADIUS)
+    eng.set_capacity(1 << 18, NKP)       # survivor limit: lists cut to the first NKP in NMS order (harness choice)
+    eng.set_dewarp_map(dmap)
+    stream = torch.cuda.Stream(device=dev)
+    job = pdist.ShardedSequence(eng, W, H, n_frames, pair_list, NKP, WORDS, dev, stream=stream)
+    # this rank's frames, made on the device: frame i of sequence s = base_s translated by (3i, i), wrap-around
+    bases = {}
+    with torch.cuda.stream(stream):
+        d_frames = torch.empty((max(1, len(job.my_frames)), H, W, 4), dtype=torch.uint16, device=dev)
+        for k, f in enumerate(job.my_frames):
+            s, i = divmod(f, FS)
+            if s not in bases:
+                bases[s] = torch.from_numpy(base_frame(W, H, 4321 + s)).to(dev)
+            roll_frames(torch, bases[s], [(3 * i, i)], out=d_frames[k:k + 1])
+    host_base0 = base_frame(W, H, 4321)
+    bases.clear()
     torch.cuda.synchronize()
-    log("[rank %d] setup %.1fs, %d frames resident (%.0f MB), %d stream(s)" % (rank, time.time() - t_setup, F, d_frames.numel() * 2 / 1e6, NS))
-    step_no = [0]
-
-    def step(ns=NS):
-        k = step_no[0] % ns
-        step_no[0] += 1
-        e, b = engs[k], bufs[k]
-        e.detect_batch_dev(d_frames, F, W, H, b["kp"], b["desc"], b["counts"], b["nraw"], CAP)
-        e.match_batch_dev(b["desc"], b["counts"], CAP, WORDS, pairlist, B, b["out"], max_count=NKP)
+    log("[rank %d/%d] setup %.1fs: %d of %d frames resident (%.0f MB), %d of %d image pairs, scaling %s"
+        % (rank, world, time.time() - t_setup, len(job.my_frames), n_frames, d_frames.numel() * 2 / 1e6, len(job.my_pairs),
+           len(pair_list), args.scaling))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, NS, NO)):
-        step(max(NS, NO))
+    for _ in range(max(1, args.warmup)):
+        job.step(d_frames)
     torch.cuda.synchronize()
-    step_no[0] = 0
-    # NMS survivors above the output capacity only flag a truncation here; anything else is fatal
-    try:
-        eng.check_status()
-    except pg.CapacityError as e:
-        log("[rank %d] note: %s" % (rank, e))
-    counts = d_counts.cpu().numpy()
-    nraw = d_nraw.cpu().numpy()
-    n_used = np.minimum(counts, NKP)
-    pairs_per_step = int(sum(int(n_used[2 * p]) * int(n_used[2 * p + 1]) for p in range(B)))
-    log("[rank %d] survivors per frame %s, raw %s" % (rank, counts.tolist(), nraw.tolist()))
+    eng.check_status()
+    counts = job.counts()
+    pairs_per_step = float(sum(int(counts[a]) * int(counts[b]) for a, b in pair_list))
+    my_pairs_per_step = float(sum(int(counts[a]) * int(counts[b]) for a, b in (pair_list[p] for p in job.my_pairs)))
+    nraw_l = job.nraw_l.cpu().numpy()[:len(job.my_frames)]
+    log("[rank %d] survivors per frame min/mean/max %d/%.0f/%d, raw hits mean %.0f"
+        % (rank, counts.min(), counts.mean(), counts.max(), nraw_l.mean() if len(nraw_l) else 0))
 
-    for e in engs[:NS]:
-        e.profile_reset()
-        e.profile_enable(True)
+    eng.profile_reset()
+    eng.profile_enable(not args.no_profile)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        job.step(d_frames)
     barrier()
     dt = time.perf_counter() - t0
-    for e in engs[:NS]:
-        e.profile_enable(False)
+    eng.profile_enable(False)
+    eng.check_status()
 
-    # the same K steps again with NO contexts in flight (events off): what stream-level overlap of the narrow
-    # kernels (scans, tails, the per-pair finish) is worth; reported beside `value`, never as `value`
-    dt_overlap = None
-    if NO > 1 and NO != NS:
-        step_no[0] = 0
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(NO)
-        barrier()
-        dt_overlap = time.perf_counter() - t0
-
-    # one exchange step: every rank's match lists -> all ranks (input of the track graph)
-    if world > 1:
-        gathered = [torch.empty_like(d_out) for _ in range(world)]
-        dist.all_gather(gathered, d_out)
-        torch.cuda.synchronize()
-
-    t = torch.tensor([dt, dt_overlap if dt_overlap is not None else 0.0], dtype=torch.float64, device=dev)
-    tot_pairs = torch.tensor([pairs_per_step], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot_pairs, op=dist.ReduceOp.SUM)
     dt_max = float(t[0].item())
-    dt_overlap_max = float(t[1].item())
-    job_pairs_per_step = float(tot_pairs.item())
 
+    rc = 0
     if rank == 0:
-        kern = {}
-        for name in ("dewarp_gray", "fast", "nms", "brief", "match_init", "ham_argmin", "match_select", "tail_fill", "match_finish"):
-            n, ms = 0, 0.0
-            for e in engs[:NS]:
-                n_e, ms_e = e.profile_get(name)
-                n, ms = n + n_e, ms + ms_e
-            if n:
-                kern[name] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / args.steps}
+        F_l, M_l = len(job.my_frames), len(job.my_pairs)
+        kern = kernel_table(eng, args.steps)
         rounds_wide, evals, evals0 = eng.match_stats()
-        log("tail debug counters (pairs, sumR, sumC, rounds, row rescans, col rescans):", eng.debug_counters())
         step_ms = dt_max / args.steps * 1e3
         match_ms = sum(kern[k]["ms_per_step"] for k in ("match_init", "ham_argmin", "match_select", "tail_fill", "match_finish") if k in kern)
         detect_ms = sum(kern[k]["ms_per_step"] for k in ("dewarp_gray", "fast", "nms", "brief") if k in kern)
         npix = W * H
-        n_raw_tot = float(nraw.sum())
-        n_kept_tot = float(n_used.sum())
+        n_raw_tot = float(nraw_l.sum())
+        n_kept_tot = float(sum(int(counts[f]) for f in job.my_frames))
 
-        def hbm(name, byts, what):
-            t = kern[name]["ms_per_step"] * 1e-3
-            return {"kernel": name, "bound": "hbm", "achieved": byts / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": byts / t / HBM_PEAK, "traffic": traffic.get(name), "algorithmic": what}
-
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")   # HBM bytes per frame from separate rocprofv3 --pmc passes
+        traffic, traffic_src = {}, None
+        tpath = os.path.join(ROOT, TRAFFIC_FILE)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             for k, v in tj.get("bytes_per_frame", {}).items():
-                traffic[k] = v * F
+                traffic[k] = v * F_l
             for k, v in tj.get("bytes_per_pair", {}).items():
-                traffic[k] = v * B
+                traffic[k] = v * M_l
+            traffic_src = ("not measured in this run: scaled from %s (separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` "
+                           "passes over the same workload, bytes per frame / per image pair x this step's counts)" % TRAFFIC_FILE)
+
+        def hbm(name, byts, what):
+            tt = kern[name]["ms_per_step"] * 1e-3
+            return {"kernel": name, "bound": "hbm", "achieved": byts / tt / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": byts / tt / HBM_PEAK, "traffic": traffic.get(name), "algorithmic": what}
+
         rooflines = {}
         if "dewarp_gray" in kern:
-            # 8 B gathered source + 4 B grey per pixel and frame; the 8 B/px map is read once per group of 4 frames
-            # (k_image.hip FB = 4), i.e. 2 B/px/frame -- the minimum this kernel's blocking allows
             per_px = 12.0 if dmap is None else 14.0
-            rooflines["dewarp_gray"] = hbm("dewarp_gray", per_px * npix * F,
-                                           "%.0f B/pixel/frame (8 gathered source + 4 grey + 8 map per 4 frames) x %d px x %d frames per launch" % (per_px, npix, F))
+            rooflines["dewarp_gray"] = hbm("dewarp_gray", per_px * npix * F_l,
+                                           "%.0f B/pixel/frame (8 gathered source + 4 grey + 8 map per 4 frames) x %d px x %d frames per launch" % (per_px, npix, F_l))
         if "fast" in kern:
             nseg = H * ((W + 63) // 64)
-            rooflines["fast"] = hbm("fast", (4.5 * npix + 8.0 * nseg) * F,
-                                    "4 B/px grey read + 0.5 B/px ballot planes + 8 B per 64-px row segment (count, then raster "
-                                    "offset), %d frames (2 launches; the raw lists are not materialised on this path)" % F)
+            rooflines["fast"] = hbm("fast", (4.5 * npix + 8.0 * nseg) * F_l,
+                                    "4 B/px grey read + 0.5 B/px ballot planes + 8 B per 64-px row segment, %d frames" % F_l)
         if "nms" in kern:
             rooflines["nms"] = hbm("nms", 8.0 * n_raw_tot + 4.0 * n_kept_tot,
                                    "integer/latency-bound stage on L2-resident lists: 8 B per raw hit in + 4 B per survivor out "
                                    "(%d raw hits, %d survivors per step)" % (n_raw_tot, n_kept_tot))
         if "brief" in kern:
             rooflines["brief"] = hbm("brief", (2.0 * P * 4 + 48.0) * n_kept_tot,
-                                     "2*P*4 B gathered + 48 B written per survivor; the kernel is bound by the L2->L1 line rate of fully divergent "
-                                     "4-byte gathers (one 128-B line per sample), not by HBM")
+                                     "2*P*4 B gathered + 48 B written per survivor (gathers are L2-resident: see profiles/ for the "
+                                     "L2 request counters)")
+        mfma = None
         if "ham_argmin" in kern:
             ops = evals * 2.0 * P
-            t = kern["ham_argmin"]["ms_per_step"] * 1e-3
-            rooflines["ham_argmin"] = {"kernel": "ham_argmin", "bound": "mfma", "achieved": ops / t / 1e12,
-                                       "peak": I8_MFMA_PEAK_OPS / 1e12, "unit": "TOP/s", "frac": ops / t / I8_MFMA_PEAK_OPS,
-                                       "traffic": traffic.get("ham_argmin"),
-                                       "algorithmic": "2*P = 512 int8 ops per descriptor-pair evaluation x %d evaluations "
-                                                      "per step over %d launches" % (evals, rounds_wide)}
+            tt = kern["ham_argmin"]["ms_per_step"] * 1e-3
+            mfma = {"kernel": "ham_argmin", "bound": "mfma", "achieved": ops / tt / 1e12,
+                    "peak": I8_MFMA_PEAK_OPS / 1e12, "unit": "TOP/s", "frac": ops / tt / I8_MFMA_PEAK_OPS,
+                    "traffic": traffic.get("ham_argmin"),
+                    "algorithmic": "2*P = 512 int8 ops per descriptor-pair evaluation x %d evaluations per step "
+                                   "(device-counted: sum over launches and image pairs of n1*n2; %d wide rounds per chunk of 128 pairs)"
+                                   % (evals, rounds_wide)}
+            rooflines["ham_argmin"] = mfma
         if detect_ms:
-            byts = 24.0 * npix * F
+            byts = 24.0 * npix * F_l
             rooflines["detect_chain"] = {"kernel": "dewarp_gray+fast+nms+brief", "bound": "hbm",
                                          "achieved": byts / (detect_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                          "frac": byts / (detect_ms * 1e-3) / HBM_PEAK, "traffic": None,
-                                         "algorithmic": "SURVEY 8d: 24 B/pixel for the fused-minimum detect stream x %d frames" % F}
+                                         "algorithmic": "SURVEY 8d: 24 B/pixel for the fused-minimum detect stream x %d frames" % F_l}
         dominant = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
-        roof = rooflines.get(dominant)
         result = {
-            "metric": "descriptor pairs matched/sec", "value": job_pairs_per_step * args.steps / dt_max,
+            "metric": "descriptor pairs matched/sec", "value": pairs_per_step * args.steps / dt_max,
             "unit": "descriptor pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 xor/popcount (int8 MFMA when enabled); f32 grey",
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "u8 (descriptor bits expanded to int8 for the MFMA distance; integer keys); f32 grey",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] x %d: %d independent 1920x1080 RGBA64 pairs per GPU per step, "
-                                   "dewarp(%s)+gray+FAST(T=0.1)+NMS(r=%d)+BRIEF-256+greedy Hamming match, %d keypoints "
-                                   "per frame (truncated to the first %d in NMS order)"
-                                   % (B, B, "off" if dmap is None else "shipped coeffs", RADIUS, NKP, NKP),
-                       "pairs_per_step_per_gpu": B, "streams": NS, "keypoints": [int(x) for x in n_used.tolist()],
-                       "raw_hits": [int(x) for x in nraw.tolist()], "parallelism": "pair-sharded x%d" % world},
-            "roofline": roof,
+            "config": {"workload": "BASELINE configs[2] (SURVEY 8d config 3) x %d: %d-frame 1920x1080 RGBA64 sequence(s), "
+                                   "dewarp(%s)+gray+FAST(T=0.1)+NMS(r=%d)+BRIEF-256 per frame, all %d ordered image pairs per sequence "
+                                   "through the greedy Hamming match, <=%d keypoints per frame (first %d in NMS order)"
+                                   % (nseq, FS, "off" if dmap is None else "shipped coeffs", RADIUS, FS * (FS - 1) // 2, NKP, NKP),
+                       "frames": n_frames, "image_pairs": len(pair_list), "frames_per_gpu": F_l, "image_pairs_per_gpu": M_l,
+                       "descriptor_pairs_per_step": pairs_per_step,
+                       "keypoints_min_mean_max": [int(counts.min()), float(counts.mean()), int(counts.max())],
+                       "raw_hits_mean": float(nraw_l.mean()) if len(nraw_l) else 0.0,
+                       "parallelism": "frames f mod %d, image pairs p mod %d; 2 all-gathers per step%s"
+                                      % (world, world, "" if world > 1 else " (elided at N = 1)")},
+            "roofline": rooflines.get(dominant),
+            "mfma": mfma,
+            "traffic_note": traffic_src,
             "rooflines": rooflines,
             "kernels": kern,
-            "overlap": ({"streams": NO, "value": job_pairs_per_step * args.steps / dt_overlap_max,
-                         "ms_per_step": dt_overlap_max / args.steps * 1e3,
-                         "note": "same K steps with %d contexts/HIP streams in flight, events off" % NO}
-                        if dt_overlap_max > 0 else None),
-            "detect": {"ms_per_step": detect_ms, "frames_per_s": F / (detect_ms * 1e-3) if detect_ms else None},
-            "match_only": {"ms_per_step": match_ms,
-                           "pairs_per_s": pairs_per_step / (match_ms * 1e-3) if match_ms else None,
+            "kernels_note": "rank 0's HIP events around every launch of the timed steps; with several chunks of 128 image pairs "
+                            "match_finish runs on a second stream beside the next chunk's wide rounds, so the groups' sum can exceed ms_per_step",
+            "detect": {"ms_per_step": detect_ms, "frames_per_s": F_l / (detect_ms * 1e-3) if detect_ms else None},
+            "match_only": {"ms_per_step_sum_of_kernels": match_ms,
+                           "wall_ms_per_step": max(step_ms - detect_ms, 0.0) if detect_ms else None,
+                           "pairs_per_s": my_pairs_per_step / (max(step_ms - detect_ms, 1e-9) * 1e-3) if detect_ms else None,
                            "wide_rounds": rounds_wide, "evaluations_per_step": evals,
-                           "mfma_frac_of_peak_on_match_stage": (evals * 2.0 * P / (match_ms * 1e-3)) / I8_MFMA_PEAK_OPS
-                           if match_ms else None},
+                           "mfma_frac_of_peak_on_match_stage": (evals * 2.0 * P / (max(step_ms - detect_ms, 1e-9) * 1e-3)) / I8_MFMA_PEAK_OPS
+                           if detect_ms else None,
+                           "note": "match stage wall = step minus the detect kernels (rank 0); SURVEY 8d's match-only definition"},
         }
-        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: at N > 1 the other ranks would sit in the barrier
+        if world == 1 and not args.no_extra_configs:
+            try:
+                result["configs"] = extra_configs(torch, pg, pdist, np, eng, dev, stream, pairs, dmap)
+                result["host_api"] = host_api_timing(torch, pg, np, eng, host_base0, dev)
+            except Exception as e:   # never lose the headline line to an add-on
+                log("extra configs failed: %r" % (e,))
+                result["configs_error"] = repr(e)
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             t1 = time.time()
-            result["cpu_baseline"] = cpu_baseline(frames_h, dmap if dmap is not None else
-                                                  np.stack(np.meshgrid(np.arange(W), np.arange(H)), axis=2).astype(np.int32),
-                                                  pairs, args.cpu_sample)
-            result["cpu_baseline"]["host_cpus"] = os.cpu_count()
+            ident = np.stack(np.meshgrid(np.arange(W), np.arange(H)), axis=2).astype(np.int32)
+            sample = roll_frames(torch, torch.from_numpy(host_base0).to(dev), [(0, 0), (3, 1)]).cpu().numpy()
+            cb = cpu_baseline(sample, dmap if dmap is not None else ident, pairs, args.cpu_sample)
+            cb["cpu_model"] = cpu_model()
+            cb["host_logical_cpus"] = os.cpu_count()
+            cb["cpus_available_to_this_process"] = len(os.sched_getaffinity(0))
             if args.cpu_procs > 1:
                 try:
-                    result["cpu_baseline"]["optimised_multicore"] = cpu_multicore(
-                        frames_h, dmap if dmap is not None else np.stack(np.meshgrid(np.arange(W), np.arange(H)), axis=2).astype(np.int32),
-                        pairs, min(args.cpu_procs, os.cpu_count() or 1))
+                    nproc = min(args.cpu_procs, len(os.sched_getaffinity(0)))
+                    cb["optimised_multicore"] = cpu_multicore(sample, dmap if dmap is not None else ident, pairs, nproc)
+                    cb["optimised_multicore"]["note"] = ("%d worker processes = the CPU share of a one-GPU box on this pool; the host "
+                                                         "has %d logical CPUs (%s): linear extrapolation to all of them = %.3g pairs/s"
+                                                         % (nproc, os.cpu_count(), cb["cpu_model"],
+                                                            cb["optimised_multicore"]["value"] * (os.cpu_count() or nproc) / nproc))
                 except Exception as e:   # a report nicety, never a reason to lose the bench line
                     log("multi-core CPU bar skipped: %r" % (e,))
+            result["cpu_baseline"] = cb
             log("cpu baseline took %.1fs" % (time.time() - t1))
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for e in engs:
-        e.close()
+    eng.close()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------
+# the other BASELINE configurations and the host-buffer entry points (rank 0, N = 1)
+# ---------------------------------------------------------------------------------------------------
+
+def _timed(torch, fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def extra_configs(torch, pg, pdist, np, eng, dev, stream, pairs_tbl, dmap):
+    out = {}
+    # -- configs[1] x 64: 64 independent 1920x1080 image pairs per step (detect 128 frames + match 64 pairs) --------
+    B = 64
+    with torch.cuda.stream(stream):
+        nb = 8
+        d_bases = [torch.from_numpy(base_frame(W, H, 1234 + b)).to(dev) for b in range(nb)]
+        d_frames = torch.empty((2 * B, H, W, 4), dtype=torch.uint16, device=dev)
+        for p in range(B):
+            k = p // nb
+            roll_frames(torch, d_bases[p % nb], [(-13 * k, 7 * k), (-13 * k + 37 + 5 * k, 7 * k + 11 + 3 * k)], out=d_frames[2 * p:2 * p + 2])
+        del d_bases
+        i32 = dict(dtype=torch.int32, device=dev)
+        kp, desc = torch.zeros((2 * B, NKP, 4), **i32), torch.zeros((2 * B, NKP, WORDS), **i32)
+        cnt, nraw, outp = torch.zeros(2 * B, **i32), torch.zeros(2 * B, **i32), torch.zeros((B, NKP, 3), **i32)
+        pl = torch.tensor([[2 * p, 2 * p + 1] for p in range(B)], **i32)
+
+        def step2():
+            eng.detect_batch_dev(d_frames, 2 * B, W, H, kp, desc, cnt, nraw, NKP)
+            eng.match_batch_dev(desc, cnt, NKP, WORDS, pl, B, outp, max_count=NKP)
+        step2()
+        torch.cuda.synchronize()
+        eng.profile_reset()
+        eng.profile_enable(True)
+        reps = 20
+        dt = _timed(torch, step2, reps)
+        eng.profile_enable(False)
+        kern = kernel_table(eng, reps + 1)
+        c = cnt.cpu().numpy()
+        npairs = float(sum(int(c[2 * p]) * int(c[2 * p + 1]) for p in range(B)))
+        _, evals, _ = eng.match_stats()
+        det_ms = sum(kern[k]["ms_per_step"] for k in ("dewarp_gray", "fast", "nms", "brief") if k in kern)
+        out["config2_batch64"] = {
+            "workload": "BASELINE configs[1] x 64: 64 independent 1920x1080 pairs per step = detect 128 frames + match 64 image pairs "
+                        "(round 1's headline workload)",
+            "pairs_per_s": npairs / dt, "ms_per_step": dt * 1e3, "detect_frames_per_s": 2 * B / (det_ms * 1e-3) if det_ms else None,
+            "kernels_ms_per_step": {k: v["ms_per_step"] for k, v in kern.items()},
+            "mfma_frac": (evals * 2.0 * P / (kern["ham_argmin"]["ms_per_step"] * 1e-3) / I8_MFMA_PEAK_OPS) if "ham_argmin" in kern else None}
+        del d_frames, kp, desc, cnt, nraw, outp
+    torch.cuda.empty_cache()
+    # -- configs[3], one-GPU window variant: 1024 x 3840x2160, image pairs 0 < j - i <= 16, 8192 keypoints ----------
+    W4, H4, F4, NKP4, R4, WIN = 3840, 2160, 1024, 8192, 22, 16
+    e4 = pg.Engine(eng.device)
+    try:
+        e4.set_brief_pairs(pairs_tbl)
+        e4.set_detect_params(THRESH, R4)
+        e4.set_capacity(1 << 20, NKP4)
+        e4.set_dewarp_coeffs(W4, H4, [3e-4, 1e-7, 0, 0, 0])   # the table is built on the device (no 66 MB upload)
+        e4.set_stream(stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            d_base = torch.from_numpy(base_frame(W4, H4, 4321)).to(dev)
+            d_frames = roll_frames(torch, d_base, [(3 * i, i) for i in range(F4)])
+            i32 = dict(dtype=torch.int32, device=dev)
+            kp, desc = torch.zeros((F4, NKP4, 4), **i32), torch.zeros((F4, NKP4, WORDS), **i32)
+            cnt, nraw = torch.zeros(F4, **i32), torch.zeros(F4, **i32)
+            pl_h = [(i, j) for i in range(F4) for j in range(i + 1, min(F4, i + WIN + 1))]
+            pl = torch.tensor(pl_h, **i32)
+            outp = torch.zeros((len(pl_h), NKP4, 3), **i32)
+            DB = 128
+
+            def det4():
+                for f0 in range(0, F4, DB):
+                    n = min(DB, F4 - f0)
+                    e4.detect_batch_dev(d_frames[f0:f0 + n], n, W4, H4, kp[f0:f0 + n], desc[f0:f0 + n], cnt[f0:f0 + n], nraw[f0:f0 + n], NKP4)
+
+            def mat4():
+                e4.match_batch_dev(desc, cnt, NKP4, WORDS, pl, len(pl_h), outp, max_count=NKP4)
+            td = _timed(torch, det4, 1)
+            e4.profile_reset()
+            e4.profile_enable(True)
+            tm = _timed(torch, mat4, 1)
+            e4.profile_enable(False)
+            kern = kernel_table(e4, 2)
+            e4.check_status()
+            c = cnt.cpu().numpy()
+            npairs = float(sum(int(c[a]) * int(c[b]) for a, b in pl_h))
+            _, evals, _ = e4.match_stats()
+            out["config4_window16"] = {
+                "workload": "BASELINE configs[3], one-GPU window variant (SURVEY 8d config 4): 1024 x 3840x2160 frames made on the device, "
+                            "image pairs 0 < j - i <= 16 (%d), r = %d, <=%d keypoints per frame" % (len(pl_h), R4, NKP4),
+                "detect_frames_per_s": F4 / td, "detect_s": td, "match_s": tm, "descriptor_pairs": npairs,
+                "match_pairs_per_s": npairs / tm, "end_to_end_pairs_per_s": npairs / (td + tm),
+                "keypoints_min_max": [int(c.min()), int(c.max())],
+                "kernels_ms": {k: v["ms_per_step"] for k, v in kern.items()},
+                "mfma_frac": (evals * 2.0 * P / (kern["ham_argmin"]["ms_per_step"] * 1e-3) / I8_MFMA_PEAK_OPS) if "ham_argmin" in kern else None}
+            del d_frames, d_base, kp, desc, cnt, nraw, outp
+    finally:
+        e4.close()
+    torch.cuda.empty_cache()
+    return out
+
+
+def host_api_timing(torch, pg, np, eng, base, dev):
+    """pgx_detect + pgx_match on ONE 1920x1080 pair from HOST buffers: the entry points the C# call sites would bind
+    (DeWarpTransformStepFactory.cs:58-60, KeyPointDetectionTransformStepFactory.cs:33-35, TestService.cs:96)."""
+    from photogrammetry_amd import synth
+    res = {}
+    f0 = base
+    f1 = synth.shift_frame(base, 37, 11)
+    pinned = [torch.empty(f0.shape, dtype=torch.uint16).pin_memory() for _ in range(2)]
+    pinned[0].numpy()[...] = f0
+    pinned[1].numpy()[...] = f1
+    for label, frames in (("pageable", (f0, f1)), ("pinned", (pinned[0].numpy(), pinned[1].numpy()))):
+        def det():
+            return [eng.detect(f, capacity=NKP) for f in frames]
+        det()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = det()
+        t_det = (time.perf_counter() - t0) / reps / 2
+        d0, d1 = r[0][1], r[1][1]
+        eng.match(d0, d1)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.match(d0, d1)
+        t_match = (time.perf_counter() - t0) / reps
+        res[label] = {"pgx_detect_ms_per_frame": t_det * 1e3, "pgx_match_ms_per_pair": t_match * 1e3,
+                      "pairs_per_s_one_pair_at_a_time": len(d0) * len(d1) / (2 * t_det + t_match),
+                      "keypoints": [len(d0), len(d1)]}
+    frame_mb = f0.nbytes / 1e6
+    res["note"] = ("synchronous host-buffer calls, one frame / one image pair at a time: each pgx_detect uploads %.1f MB (PCIe Gen5 x16 "
+                   "spec 63 GB/s = %.2f ms at best) and waits; the batched _dev entry points above are the throughput path"
+                   % (frame_mb, frame_mb / 63e3 * 1e3))
+    return res
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus < 1:
+        log("bench.py: --gpus must be >= 1")
+        return 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -79,7 +79,11 @@ int pgx_get_dewarp_map(pgx_ctx *ctx, int32_t *uv_out, int W, int H);
 int pgx_set_brief_pairs(pgx_ctx *ctx, const int32_t *pairs, int P);
 /* KeypointDetectionOptions.Threshold, RedundantKeypointEliminationOptions.SuppressionRadius. */
 int pgx_set_detect_params(pgx_ctx *ctx, float threshold, int suppression_radius);
-/* Per-frame capacities of the fused detect path: raw FAST hits kept for NMS, and survivors. */
+/* Per-frame limits of the fused detect path.  max_raw_per_frame: raw FAST hits kept for NMS (more raise
+ * PGX_E_CAPACITY).  max_keypoints_per_frame: survivor LIMIT -- a frame's list is cut to its first
+ * max_keypoints_per_frame entries in NMS order without an error (a harness-side truncation: the reference has
+ * no cap; default 2^20 = none).  Survivors beyond a call's own `capacity` still raise
+ * PGX_E_CAPACITY. */
 int pgx_set_capacity(pgx_ctx *ctx, int max_raw_per_frame, int max_keypoints_per_frame);
 
 /* ---- stage-granular host entry points (one reference function each) ------------------ */
@@ -112,6 +116,11 @@ int pgx_detect(pgx_ctx *ctx, const uint16_t *rgba64, int W, int H,
                pgx_keypoint *kp_out, uint32_t *desc_out, int capacity, int *n_out, int *n_raw);
 
 /* ---- device-resident batched entry points (asynchronous on the context's stream) ------ */
+/* Stream hand-off contract: the context's own stream is NON-BLOCKING (it does not order against the null stream
+ * or any other stream).  Every "_dev" input must be complete, and every output buffer free to be written, on the
+ * context's stream when the call is made: either hand the library the stream that produced them
+ * (pgx_set_stream) or synchronise the producer first.  Results are defined after pgx_check_status() (or after
+ * the caller synchronises that stream). */
 /* F frames [F][H][W][4] uint16 in HBM -> per frame up to `capacity` survivors.
  * d_kp [F][capacity], d_desc [F][capacity][words], d_counts [F], d_nraw [F] (all device). */
 int pgx_detect_batch_dev(pgx_ctx *ctx, const uint16_t *d_rgba64, int F, int W, int H,

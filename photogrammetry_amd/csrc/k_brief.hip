@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_brief_kept(const float *__restrict__ gr
                                                     const int32_t *__restrict__ n_kept, int kp_cap,
                                                     const int4 *__restrict__ pairs, int P, int words,
                                                     pgx_keypoint *__restrict__ kp_out, uint32_t *__restrict__ desc_out,
-                                                    int32_t *__restrict__ counts_out, int nframes)
+                                                    int32_t *__restrict__ counts_out, int nframes, int out_stride)
 {
     __shared__ uint32_t wbuf[4][MAX_WORDS + 2];
     // XCD-aware block -> (frame, keypoint block) map: consecutive workgroup ids are dealt round-robin to
@@ -121,10 +121,10 @@ __global__ __launch_bounds__(256) void k_brief_kept(const float *__restrict__ gr
         pgx_keypoint kp;
         kp.x = x; kp.y = y; kp.fast_score = raw_score[(size_t)f * raw_cap + ri];
         kp.value = g[(size_t)y * W + x]; // Keypoint.cs:26
-        kp_out[(size_t)f * kp_cap + k] = kp;
+        kp_out[(size_t)f * out_stride + k] = kp;
     }
-    if (P == 256) brief_256(g, W, H, x, y, pairs, desc_out + ((size_t)f * kp_cap + k) * 8);
-    else brief_one(g, W, H, x, y, pairs, P, words, wbuf[wv], desc_out + ((size_t)f * kp_cap + k) * words);
+    if (P == 256) brief_256(g, W, H, x, y, pairs, desc_out + ((size_t)f * out_stride + k) * 8);
+    else brief_one(g, W, H, x, y, pairs, P, words, wbuf[wv], desc_out + ((size_t)f * out_stride + k) * words);
 }
 
 __global__ __launch_bounds__(256) void k_brief_list(const float *__restrict__ gray, int W, int H,
@@ -145,13 +145,13 @@ __global__ __launch_bounds__(256) void k_brief_list(const float *__restrict__ gr
 void pgx_launch_brief(hipStream_t s, const float *gray, int F, int W, int H, const uint32_t *raw_xy,
                       const int32_t *raw_score, int raw_cap, const uint32_t *order, const int32_t *n_kept,
                       int kp_cap, const int32_t *pairs, int P, pgx_keypoint *kp_out, uint32_t *desc_out,
-                      int32_t *counts_out)
+                      int32_t *counts_out, int out_stride)
 {
     if (F <= 0 || kp_cap <= 0) return;
     const int words = (P + 31) / 32;
     hipLaunchKernelGGL(k_brief_kept, dim3(((kp_cap + 3) / 4) * F), dim3(256), 0, s, gray, W, H, raw_xy, raw_score,
                        raw_cap, order, n_kept, kp_cap, reinterpret_cast<const int4 *>(pairs), P, words, kp_out,
-                       desc_out, counts_out, F);
+                       desc_out, counts_out, F, out_stride);
 }
 
 void pgx_launch_brief_list(hipStream_t s, const float *gray, int W, int H, const pgx_keypoint *kps, int n,

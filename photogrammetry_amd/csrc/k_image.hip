@@ -30,11 +30,14 @@ __global__ __launch_bounds__(256) void k_dewarp_gray(const uint2 *__restrict__ r
     const int f0 = blockIdx.y * FB;
     const int nf = F - f0 < FB ? F - f0 : FB; // block-uniform
     const size_t ngroups = (npix + 3) / 4;
+    // 16-byte accesses at frame f's base need f * npix to be a multiple of 4 pixels: odd frame sizes in a batch
+    // take the scalar path (block-uniform)
+    const bool vec = (npix & 3) == 0 || F == 1;
     bool oob = false;
     for (size_t grp = (size_t)blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups;
          grp += (size_t)gridDim.x * blockDim.x) {
         const size_t i0 = grp * 4;
-        if (i0 + 3 < npix) {
+        if (vec && i0 + 3 < npix) {
             size_t so[4]; // source offsets of the four output pixels, the same in every frame
             bool ok[4];
             if (HAS_MAP) {
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void k_dewarp_gray(const uint2 *__restrict__ r
                 }
             }
         } else {
-            for (size_t i = i0; i < npix; i++) {
+            for (size_t i = i0; i < npix && i < i0 + 4; i++) {
                 size_t o = i;
                 bool okk = true;
                 if (HAS_MAP) {

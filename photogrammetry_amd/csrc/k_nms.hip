@@ -835,7 +835,7 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *raw_score_all,
                                                  int radius, unsigned char *ws_all, size_t ws_stride,
                                                  uint32_t *__restrict__ order_all, int32_t *__restrict__ n_kept_all,
                                                  int kp_cap, int *status, int round0, uint32_t *raw_xy_out,
-                                                 int32_t *raw_score_out)
+                                                 int32_t *raw_score_out, int kp_soft)
 {
     extern __shared__ unsigned long long lds_keys[];
     __shared__ uint32_t wsum[NT / 64];
@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *raw_score_all,
     }
     if (tid == 0) {
         n_kept_all[f] = (int32_t)(nacc < (uint32_t)kp_cap ? nacc : (uint32_t)kp_cap);
-        if (nacc > (uint32_t)kp_cap) atomicOr(status, (int)PGX_ST_KP_CAP);
+        if (nacc > (uint32_t)kp_cap && !kp_soft) atomicOr(status, (int)PGX_ST_KP_CAP); // a soft limit cuts the list silently
     }
 }
 
@@ -1063,7 +1063,7 @@ struct NmsLaunch {
     uint32_t *raw_xy; int32_t *raw_score; const int32_t *n_raw;
     int F, n_cap, W, H, radius;
     unsigned char *ws; size_t ws_stride;
-    uint32_t *order; int32_t *n_kept; int kp_cap; int *status;
+    uint32_t *order; int32_t *n_kept; int kp_cap; int kp_soft = 0; int *status;
     const unsigned long long *seg; const uint32_t *segoff;
     NmsLayout L;
     bool planes;
@@ -1120,7 +1120,7 @@ void nms_finish(const NmsLaunch &a, int round0)
         attr_set = true;
     }
     hipLaunchKernelGGL(k_nms_tail, dim3(a.F), dim3(NT), SORT_LDS_MAX * 8, a.s, a.raw_score, a.n_raw, a.n_cap, a.L, a.radius, a.ws,
-                       a.ws_stride, a.order, a.n_kept, a.kp_cap, a.status, round0, a.raw_xy, a.raw_score);
+                       a.ws_stride, a.order, a.n_kept, a.kp_cap, a.status, round0, a.raw_xy, a.raw_score, a.kp_soft);
 }
 
 NmsLaunch nms_args(hipStream_t s, uint32_t *raw_xy, int32_t *raw_score, const int32_t *n_raw, int F, int n_cap,
@@ -1148,11 +1148,13 @@ int wide_rounds_default()
 // asynchronous form (fused detect path): a fixed number of whole-chip rounds, the tail kernel finishes
 void pgx_launch_nms(hipStream_t s, uint32_t *raw_xy, int32_t *raw_score, const int32_t *n_raw, int F,
                     int n_cap, int W, int H, int radius, void *wsv, size_t ws_stride, uint32_t *order,
-                    int32_t *n_kept, int kp_cap, int *status, const unsigned long long *seg, const uint32_t *segoff)
+                    int32_t *n_kept, int kp_cap, int *status, const unsigned long long *seg, const uint32_t *segoff,
+                    bool kp_soft)
 {
     if (F <= 0) return;
-    const NmsLaunch a = nms_args(s, raw_xy, raw_score, n_raw, F, n_cap, W, H, radius, wsv, ws_stride, order, n_kept, kp_cap,
+    NmsLaunch a = nms_args(s, raw_xy, raw_score, n_raw, F, n_cap, W, H, radius, wsv, ws_stride, order, n_kept, kp_cap,
                                  status, seg, segoff);
+    a.kp_soft = kp_soft ? 1 : 0;
     int used = 0;
     if (radius >= 0) {
         nms_setup(a);

@@ -77,7 +77,11 @@ int enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_
     HIPCHK(c, c->ws_rawscore.ensure((size_t)F * raw_cap * 4));
     const size_t nms_stride = pgx_nms_ws_bytes(W, H, c->radius, raw_cap, true);
     HIPCHK(c, c->ws_nms.ensure((size_t)F * nms_stride));
-    HIPCHK(c, c->ws_order.ensure((size_t)F * cap * 4));
+    // pgx_set_capacity's survivor limit: lists are cut to their first kp_cap entries (NMS order) without an error;
+    // only an overflow of the caller's own `cap` raises PGX_E_CAPACITY
+    const bool kp_soft = c->kp_cap <= cap;
+    const int kp_eff = kp_soft ? c->kp_cap : cap;
+    HIPCHK(c, c->ws_order.ensure((size_t)F * kp_eff * 4));
     HIPCHK(c, c->ws_nkept.ensure((size_t)F * 4));
 
     float *gray = c->ws_gray.as<float>();
@@ -97,13 +101,13 @@ int enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_
         ProfScope ps(c, "nms");
         pgx_launch_nms(c->stream, c->ws_rawxy.as<uint32_t>(), c->ws_rawscore.as<int32_t>(), d_nraw, F, raw_cap, W, H,
                        c->radius, c->ws_nms.p, nms_stride, c->ws_order.as<uint32_t>(), c->ws_nkept.as<int32_t>(),
-                       cap, c->d_status, c->ws_seg.as<unsigned long long>(), c->ws_segoff.as<uint32_t>());
+                       kp_eff, c->d_status, c->ws_seg.as<unsigned long long>(), c->ws_segoff.as<uint32_t>(), kp_soft);
     }
     {
         ProfScope ps(c, "brief");
         pgx_launch_brief(c->stream, gray, F, W, H, c->ws_rawxy.as<uint32_t>(), c->ws_rawscore.as<int32_t>(), raw_cap,
-                         c->ws_order.as<uint32_t>(), c->ws_nkept.as<int32_t>(), cap, c->d_pairs.as<int32_t>(), c->P,
-                         d_kp, d_desc, d_counts);
+                         c->ws_order.as<uint32_t>(), c->ws_nkept.as<int32_t>(), kp_eff, c->d_pairs.as<int32_t>(), c->P,
+                         d_kp, d_desc, d_counts, cap);
     }
     HIPCHK(c, hipGetLastError());
     return PGX_OK;

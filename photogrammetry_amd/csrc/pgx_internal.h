@@ -70,7 +70,7 @@ struct pgx_ctx {
     bool map_set = false;
     DevBuf d_map;
     int raw_cap = 1 << 17;
-    int kp_cap = 8192;
+    int kp_cap = 1 << PGX_IDX_BITS; // soft survivor limit of the fused path (pgx_set_capacity); default: none
 
     // status words: [0] sticky error bits
     int *d_status = nullptr;
@@ -161,7 +161,8 @@ void pgx_launch_nms(hipStream_t s, uint32_t *raw_xy, int32_t *raw_score, const i
                     int F, int n_cap, int W, int H, int radius, void *ws, size_t ws_stride,
                     uint32_t *order /*[F][kp_cap]*/, int32_t *n_kept /*[F]*/, int kp_cap, int *status,
                     const unsigned long long *seg = nullptr /* FAST planes: enables atomic-free binning */,
-                    const uint32_t *segoff = nullptr);
+                    const uint32_t *segoff = nullptr,
+                    bool kp_soft = false /* true: kp_cap is the caller's soft limit, lists are cut without PGX_ST_KP_CAP */);
 // stage API (one list, host waits): whole-chip rounds until nothing is left undecided, see k_nms.hip
 hipError_t pgx_launch_nms_sync(hipStream_t s, const uint32_t *raw_xy, const int32_t *raw_score, const int32_t *n_raw,
                                int n_cap, int W, int H, int radius, void *ws, size_t ws_stride, uint32_t *order,
@@ -170,9 +171,9 @@ hipError_t pgx_launch_nms_sync(hipStream_t s, const uint32_t *raw_xy, const int3
 // k_brief.hip
 void pgx_launch_brief(hipStream_t s, const float *gray, int F, int W, int H,
                       const uint32_t *raw_xy, const int32_t *raw_score, int raw_cap,
-                      const uint32_t *order, const int32_t *n_kept, int kp_cap,
+                      const uint32_t *order, const int32_t *n_kept, int kp_cap /* order stride and list bound */,
                       const int32_t *pairs, int P,
-                      pgx_keypoint *kp_out, uint32_t *desc_out, int32_t *counts_out);
+                      pgx_keypoint *kp_out, uint32_t *desc_out, int32_t *counts_out, int out_stride /* slots per frame in kp_out/desc_out */);
 // descriptors for an explicit keypoint list (stage API)
 void pgx_launch_brief_list(hipStream_t s, const float *gray, int W, int H, const pgx_keypoint *kps, int n,
                            const int32_t *pairs, int P, uint32_t *desc_out);

@@ -123,3 +123,84 @@ def build_track_graph(counts_all, pair_list, matches_all, max_dist=64):
     for p, (a, b) in enumerate(pair_list):
         g.add_pair(a, b, m[p][:int(c[a])], max_dist)
     return g
+
+
+# ---- the four phases on this rank's GPU ------------------------------------------------------------
+
+def slot_of(index, world, nslots):
+    """Position of global item `index` in a rank-major gathered buffer [world][nslots]: its owner's
+    block, then its place in the owner's list.  all_gather_into_tensor leaves the blocks in rank
+    order, so nothing is permuted in memory: consumers address through this map."""
+    return (index % world) * nslots + index // world
+
+
+class ShardedSequence:
+    """One multi-frame job on G ranks, device-resident end to end:
+
+      phase 1  pgx_detect_batch_dev on the frames this rank owns (frame f -> rank f mod G), written
+               straight into this rank's block of the gathered descriptor buffer
+      phase 2  all-gather (in place) of the fixed-size per-frame records: descriptors + counts
+      phase 3  pgx_match_batch_dev on the image pairs this rank owns (pair p -> rank p mod G)
+      phase 4  all-gather (in place) of the fixed-size match lists (KeypointMatching.cs:38: always
+               exactly N1 entries per image pair, padded to `nkp`)
+
+    With G == 1 the collectives vanish and the same code runs.  All buffers are allocated once;
+    `step()` only enqueues (pgx kernels and the collectives share `stream`).  Frames are addressed in
+    the gathered buffers through slot_of(); the pair list handed to the matcher is pre-mapped."""
+
+    def __init__(self, engine, W, H, n_frames, pair_list, nkp, words, device, stream=None, group=None):
+        self.e, self.W, self.H, self.nkp, self.words = engine, W, H, nkp, words
+        self.rank, self.world = _world()
+        self.group = group
+        self.n_frames, self.pair_list = n_frames, list(pair_list)
+        G = self.world
+        self.fs = slots(n_frames, G)
+        self.ps = slots(len(self.pair_list), G)
+        self.my_frames = local_items(n_frames, self.rank, G)
+        self.my_pairs = local_items(len(self.pair_list), self.rank, G)
+        device = torch.device(device)
+        self.on_gpu = device.type == "cuda"   # CPU tensors + gloo: the world_size-2 tests, with a stand-in engine
+        self.stream = (stream if stream is not None else torch.cuda.current_stream(device)) if self.on_gpu else None
+        i32 = dict(dtype=torch.int32, device=device)
+        self.desc_all = torch.zeros((G * self.fs, nkp, words), **i32)
+        self.counts_all = torch.zeros(G * self.fs, **i32)
+        self.out_all = torch.zeros((G * self.ps, nkp, 3), **i32)
+        self.kp_l = torch.zeros((self.fs, nkp, 4), **i32)
+        self.nraw_l = torch.zeros(self.fs, **i32)
+        lo_f, lo_p = self.rank * self.fs, self.rank * self.ps
+        self.desc_l = self.desc_all[lo_f:lo_f + self.fs]
+        self.counts_l = self.counts_all[lo_f:lo_f + self.fs]
+        self.out_l = self.out_all[lo_p:lo_p + self.ps]
+        mapped = [[slot_of(a, G, self.fs), slot_of(b, G, self.fs)] for a, b in (self.pair_list[p] for p in self.my_pairs)]
+        self.pairlist_l = torch.tensor(mapped if mapped else [[0, 0]], **i32)
+        if self.on_gpu:
+            engine.set_stream(self.stream.cuda_stream)
+
+    def step(self, d_frames_local):
+        """d_frames_local: uint16 [len(my_frames)][H][W][4] resident on this rank's GPU."""
+        import contextlib
+        nf, npr = len(self.my_frames), len(self.my_pairs)
+        with (torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()):
+            if nf:
+                self.e.detect_batch_dev(d_frames_local, nf, self.W, self.H, self.kp_l, self.desc_l, self.counts_l,
+                                        self.nraw_l, self.nkp)
+            if self.world > 1:
+                dist.all_gather_into_tensor(self.desc_all, self.desc_l, group=self.group)
+                dist.all_gather_into_tensor(self.counts_all, self.counts_l, group=self.group)
+            if npr:
+                self.e.match_batch_dev(self.desc_all, self.counts_all, self.nkp, self.words, self.pairlist_l, npr,
+                                       self.out_l, max_count=self.nkp)
+            if self.world > 1:
+                dist.all_gather_into_tensor(self.out_all, self.out_l, group=self.group)
+
+    # -- views for consumers (host side) ---------------------------------------------------------
+    def counts(self):
+        """Per-frame counts in global frame order."""
+        c = self.counts_all.cpu().numpy()
+        return np.array([c[slot_of(f, self.world, self.fs)] for f in range(self.n_frames)], dtype=np.int32)
+
+    def descriptors(self, frame):
+        return self.desc_all[slot_of(frame, self.world, self.fs)]
+
+    def matches(self, pair_index):
+        return self.out_all[slot_of(pair_index, self.world, self.ps)]

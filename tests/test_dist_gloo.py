@@ -133,3 +133,76 @@ def test_track_graph_rejects_same_frame_merges():
     g.add_pair(1, 2, [[0, 1, 3]], max_dist=10)
     g.add_pair(0, 2, [[1, 1, 2]], max_dist=10)                   # would put (0,0) and (0,1) in one track
     assert g.tracks() == [[(0, 0), (1, 0), (2, 1)]]
+
+
+# ---- ShardedSequence (the class bench.py runs on the GPUs) on CPU tensors with a stand-in engine ----------
+
+class _OracleEngine:
+    """Stand-in for pg.Engine in the gloo test: the same two batched entry points, computed by the oracle on CPU
+    tensors.  What is under test is ShardedSequence's sharding, slot addressing and in-place all-gathers."""
+
+    def __init__(self, pairs):
+        self.pairs = pairs
+
+    def detect_batch_dev(self, frames, F, W_, H_, kp, desc, counts, nraw, cap):
+        for k in range(F):
+            d, n = _detect(frames[k].numpy(), self.pairs)
+            desc[k] = torch.from_numpy(d[:cap])
+            counts[k] = min(n, cap)
+
+    def match_batch_dev(self, desc, counts, stride, words, pairlist, M, out, max_count=None):
+        d, c = desc.numpy(), counts.numpy()
+        for m in range(M):
+            a, b = int(pairlist[m, 0]), int(pairlist[m, 1])
+            out[m] = torch.from_numpy(_match(d[a], int(c[a]), d[b], int(c[b])))
+
+
+def _seq_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pairs = cref.gaussian_pairs(0, 20, 256)
+        fr = _frames()
+        pl = pdist.all_pairs(N_FRAMES)
+        job = pdist.ShardedSequence(_OracleEngine(pairs), W, H, N_FRAMES, pl, CAP, 8, "cpu")
+        mine = torch.from_numpy(np.stack([fr[f] for f in job.my_frames]))
+        job.step(mine)
+        job.step(mine)   # a second step over the same buffers must give the same answer
+        desc = np.stack([job.descriptors(f).numpy() for f in range(N_FRAMES)])
+        out = np.stack([job.matches(p).numpy() for p in range(len(pl))])
+        q.put((rank, desc, job.counts(), out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_sequence_equals_single_process(world):
+    """5 frames / 10 image pairs over 2 and 3 ranks (uneven shares: padding slots on the last ranks)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_seq_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    desc, counts, pl, matches = _single_process()
+    for rank, d, c, m in results:
+        assert (c == counts).all(), rank
+        assert (d == desc).all(), rank
+        assert (m == matches).all(), rank
+
+
+def test_slot_of_is_a_bijection():
+    for world in (1, 2, 3, 8):
+        for n in (1, 5, 64, 2016):
+            ns = pdist.slots(n, world)
+            got = sorted(pdist.slot_of(i, world, ns) for i in range(n))
+            assert len(set(got)) == n and got[-1] < world * ns
+            for r in range(world):   # rank r's block holds exactly its items, in ownership order
+                assert [pdist.slot_of(i, world, ns) for i in pdist.local_items(n, r, world)] == \
+                       list(range(r * ns, r * ns + len(pdist.local_items(n, r, world))))

@@ -47,6 +47,7 @@ def test_detect_batch_matches_oracle(engine, F, radius, with_map):
     d_desc = torch.zeros((F, CAP, 8), dtype=torch.int32, device=DEV)
     d_counts = torch.full((F,), -1, dtype=torch.int32, device=DEV)
     d_nraw = torch.full((F,), -1, dtype=torch.int32, device=DEV)
+    torch.cuda.synchronize()   # torch's fills run on ITS stream; the engine's non-blocking stream does not order against it
     engine.detect_batch_dev(d_frames, F, W, H, d_kp, d_desc, d_counts, d_nraw, CAP)
     engine.check_status()
     kp = d_kp.cpu().numpy()
@@ -73,6 +74,7 @@ def _match_batch(engine, descs, counts, pairlist, stride, max_count=None):
     d_counts = torch.tensor(counts, dtype=torch.int32, device=DEV)
     d_pl = torch.tensor(pairlist, dtype=torch.int32, device=DEV)
     d_out = torch.full((len(pairlist), stride, 3), -7, dtype=torch.int32, device=DEV)
+    torch.cuda.synchronize()   # see pgx.h: "_dev" buffers must be ready on, or ordered against, the context's stream
     engine.match_batch_dev(d_desc, d_counts, stride, 8, d_pl, len(pairlist), d_out, max_count=max_count)
     _match_batch.keepalive = (d_desc, d_counts, d_pl)   # the launch is asynchronous: inputs must outlive it
     return d_out
@@ -180,6 +182,7 @@ def test_detect_full_size_frames_vs_oracle(engine, radius):
     d_desc = torch.zeros((F, CAP, 8), dtype=torch.int32, device=DEV)
     d_counts = torch.zeros(F, dtype=torch.int32, device=DEV)
     d_nraw = torch.zeros(F, dtype=torch.int32, device=DEV)
+    torch.cuda.synchronize()
     engine.detect_batch_dev(d_frames, F, W, H, d_kp, d_desc, d_counts, d_nraw, CAP)
     engine.check_status()
     kp = d_kp.cpu().numpy()
@@ -213,6 +216,7 @@ def test_detect_4k_frame_vs_oracle(engine):
     d_desc = torch.zeros((1, CAP, 8), dtype=torch.int32, device=DEV)
     d_counts = torch.zeros(1, dtype=torch.int32, device=DEV)
     d_nraw = torch.zeros(1, dtype=torch.int32, device=DEV)
+    torch.cuda.synchronize()
     engine.detect_batch_dev(d_frames, 1, W, H, d_kp, d_desc, d_counts, d_nraw, CAP)
     engine.check_status()
     kept, edesc, n_raw = _oracle_detect(frame, dmap, pairs, T, radius, CAP)
@@ -243,6 +247,7 @@ def test_detect_dense_noise_frame_vs_oracle(engine, radius):
     d_desc = torch.zeros((1, CAP, 8), dtype=torch.int32, device=DEV)
     d_counts = torch.zeros(1, dtype=torch.int32, device=DEV)
     d_nraw = torch.zeros(1, dtype=torch.int32, device=DEV)
+    torch.cuda.synchronize()
     engine.detect_batch_dev(d_frames, 1, W, H, d_kp, d_desc, d_counts, d_nraw, CAP)
     engine.check_status()
     kept, edesc, n_raw = _oracle_detect(frame, None, pairs, T, radius, CAP)
@@ -275,6 +280,7 @@ def test_two_contexts_in_flight_are_independent():
                          counts=torch.zeros(4, dtype=torch.int32, device=DEV),
                          nraw=torch.zeros(4, dtype=torch.int32, device=DEV),
                          out=torch.zeros((3, CAP, 3), dtype=torch.int32, device=DEV)))
+    torch.cuda.synchronize()
     for _ in range(3):   # several rounds in flight on both streams
         for e, o in zip(engs, outs):
             e.detect_batch_dev(d_frames, 4, W, H, o["kp"], o["desc"], o["counts"], o["nraw"], CAP)

@@ -1,0 +1,225 @@
+"""GPU parity tests for the configurations beyond one image pair:
+
+  * the class bench.py runs (dist.ShardedSequence, world 1) on a config-3-shaped sequence of full-size 1920x1080
+    frames, all ordered image pairs, EVERY pair against the oracle's sorted-edge-scan matcher;
+  * one 8192 x 8192 match (BASELINE configs[3]'s keypoint count);
+  * one pair of 3840x2160 frames, detect -> match end to end;
+  * >= 3 workspace chunks of image pairs WITH wide (whole-chip MFMA) rounds, so the two-stream overlap of
+    enqueue_match (wide rounds of chunk i + 1 beside the per-pair finish of chunk i) runs for real;
+  * a batch of odd-sized frames (W*H not a multiple of 4) through pgx_detect_batch_dev.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+from photogrammetry_amd import dist as pdist
+from photogrammetry_amd import synth
+import photogrammetry_amd as pg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = np.float32(0.1)
+
+
+@pytest.fixture(scope="module")
+def engine():
+    e = pg.Engine(0)
+    yield e
+    e.close()
+
+
+def _oracle_detect(frame, dmap, pairs, radius, cap):
+    src = cref.apply_distortion(frame, dmap) if dmap is not None else frame
+    g = cref.gray(src)
+    raw = cref.detect(g, T)
+    kept = raw[cref.nms(raw, radius)][:cap]
+    return kept, cref.brief(g, np.stack([kept["x"], kept["y"]], 1), pairs), len(raw)
+
+
+def _same(got, exp):
+    return bool((got[:, 0] == exp["k1"]).all() and (got[:, 1] == exp["k2"]).all() and (got[:, 2] == exp["dist"]).all())
+
+
+def test_sharded_sequence_world1_config3_shape(engine):
+    """8 frames of 1920x1080 (frame_i = frame_0 translated by (3i, i)), NMS r = 16, lists cut to
+    4096 keypoints by the survivor limit, all 28 ordered image pairs: detect of two frames and EVERY match list
+    against the oracle."""
+    W, H, NKP, radius, F = 1920, 1080, 4096, 16, 8
+    pairs = pg.make_brief_pairs(0, 50, 256)
+    dmap = pg.build_dewarp_map(W, H, [3e-4, 1e-7, 0, 0, 0])
+    engine.set_brief_pairs(pairs)
+    engine.set_detect_params(T, radius)
+    engine.set_capacity(1 << 18, NKP)
+    engine.set_dewarp_map(dmap)
+    base = synth.make_frame(W, H, seed=4321, n_shapes=20000)
+    d_base = torch.from_numpy(base).to(DEV)
+    d_frames = torch.empty((F, H, W, 4), dtype=torch.uint16, device=DEV)
+    for i in range(F):   # wrap-around translation, as bench.py makes them
+        d_frames.view(torch.int64)[i] = torch.roll(d_base.view(torch.int64), shifts=(i % H, (3 * i) % W), dims=(0, 1))
+    pl = pdist.all_pairs(F)
+    stream = torch.cuda.Stream(device=DEV)
+    job = pdist.ShardedSequence(engine, W, H, F, pl, NKP, 8, DEV, stream=stream)
+    torch.cuda.synchronize()
+    job.step(d_frames)
+    job.step(d_frames)          # buffers are reused step after step
+    engine.check_status()       # the survivor limit cuts silently: no CapacityError although > 4096 survive
+    counts = job.counts()
+    assert counts.max() == NKP and counts.min() > 3500, counts   # some frames keep a few less than the limit
+    desc = [job.descriptors(f).cpu().numpy().view(np.uint32)[:counts[f]] for f in range(F)]
+    frames_h = d_frames.cpu().numpy()
+    for f in (0, 5):
+        kept, edesc, n_raw = _oracle_detect(frames_h[f], dmap, pairs, radius, NKP)
+        n = len(kept)
+        assert n == counts[f] and int(job.nraw_l[f]) == n_raw
+        kp = job.kp_l[f].cpu().numpy()
+        assert (kp[:n, 0] == kept["x"]).all() and (kp[:n, 1] == kept["y"]).all()
+        assert (desc[f] == edesc).all()
+    for m, (a, b) in enumerate(pl):
+        got = job.matches(m).cpu().numpy()[:counts[a]]
+        assert _same(got, cref.match_sorted(desc[a], desc[b])), (a, b)
+    engine.set_stream(0)
+    engine.set_dewarp_map(None)
+    engine.set_capacity(1 << 17, 1 << 20)
+
+
+def _match_dev(engine, descs, pl, stride, max_count=None):
+    F = len(descs)
+    d = np.zeros((F, stride, 8), dtype=np.uint32)
+    for f in range(F):
+        d[f, :len(descs[f])] = descs[f]
+    d_desc = torch.from_numpy(d.view(np.int32)).to(DEV)
+    d_counts = torch.tensor([len(x) for x in descs], dtype=torch.int32, device=DEV)
+    d_pl = torch.tensor(pl, dtype=torch.int32, device=DEV)
+    d_out = torch.full((len(pl), stride, 3), -7, dtype=torch.int32, device=DEV)
+    torch.cuda.synchronize()
+    engine.match_batch_dev(d_desc, d_counts, stride, 8, d_pl, len(pl), d_out, max_count=max_count)
+    engine.check_status()
+    return d_out.cpu().numpy()
+
+
+def test_match_8192_squared_vs_oracle(engine):
+    """BASELINE configs[3]'s list length: uniform-random (tie-heavy: distances ~ Binomial(256, 1/2)) and a
+    true-correspondence pair (permuted copy with 15 % of the bits flipped), both directions."""
+    N = 8192
+    a = synth.random_descriptors(N, 8, 81)
+    b = synth.random_descriptors(N, 8, 82)
+    t1, t2, _ = synth.true_match_descriptors(N, 8, 83)
+    out = _match_dev(engine, [a, b, t1, t2], [(0, 1), (1, 0), (2, 3), (3, 2)], N)
+    sets = [a, b, t1, t2]
+    for m, (x, y) in enumerate([(0, 1), (1, 0), (2, 3), (3, 2)]):
+        assert _same(out[m][:N], cref.match_sorted(sets[x], sets[y])), (x, y)
+    rounds, evals, evals0 = engine.match_stats()
+    assert rounds >= 3 and evals0 == 4 * N * N
+
+
+def test_detect_and_match_4k_pair_end_to_end(engine):
+    """Two 3840x2160 frames (the second translated by (37, 11)), r = 22, lists cut to 8192: both detect lists and
+    the match list against the oracle."""
+    W, H, NKP, radius = 3840, 2160, 8192, 22
+    pairs = pg.make_brief_pairs(0, 50, 256)
+    dmap = pg.build_dewarp_map(W, H, [3e-4, 1e-7, 0, 0, 0])
+    engine.set_brief_pairs(pairs)
+    engine.set_detect_params(T, radius)
+    engine.set_capacity(1 << 20, NKP)
+    engine.set_dewarp_map(dmap)
+    f0 = synth.make_frame(W, H, seed=5, n_shapes=80000)
+    frames = np.stack([f0, synth.shift_frame(f0, 37, 11)])
+    d_frames = torch.from_numpy(frames).to(DEV)
+    i32 = dict(dtype=torch.int32, device=DEV)
+    d_kp, d_desc = torch.zeros((2, NKP, 4), **i32), torch.zeros((2, NKP, 8), **i32)
+    d_counts, d_nraw = torch.zeros(2, **i32), torch.zeros(2, **i32)
+    d_pl = torch.tensor([[0, 1]], **i32)
+    d_out = torch.zeros((1, NKP, 3), **i32)
+    torch.cuda.synchronize()
+    engine.detect_batch_dev(d_frames, 2, W, H, d_kp, d_desc, d_counts, d_nraw, NKP)
+    engine.match_batch_dev(d_desc, d_counts, NKP, 8, d_pl, 1, d_out, max_count=NKP)
+    engine.check_status()
+    desc = d_desc.cpu().numpy().view(np.uint32)
+    exp = [_oracle_detect(frames[f], dmap, pairs, radius, NKP) for f in range(2)]
+    for f in range(2):
+        kept, edesc, n_raw = exp[f]
+        assert len(kept) == NKP and int(d_counts[f]) == NKP and int(d_nraw[f]) == n_raw
+        kp = d_kp[f].cpu().numpy()
+        assert (kp[:, 0] == kept["x"]).all() and (kp[:, 1] == kept["y"]).all() and (kp[:, 2] == kept["fast_score"]).all()
+        assert (desc[f] == edesc).all()
+    assert _same(d_out[0].cpu().numpy(), cref.match_sorted(exp[0][1], exp[1][1]))
+    engine.set_dewarp_map(None)
+    engine.set_capacity(1 << 17, 1 << 20)
+
+
+def test_match_three_chunks_with_wide_rounds(engine):
+    """300 image pairs (3 workspace chunks of 128) over 25 descriptor sets of 1100-1900 entries (> 1024, so every chunk
+    runs whole-chip MFMA rounds on one stream while the previous chunk's per-pair finish runs on the other), with
+    near-duplicate descriptors across sets (tie-heavy).  Every pair against the oracle; run with the profiling hooks on."""
+    rng = np.random.default_rng(18)
+    F = 25
+    sizes = [int(x) for x in rng.integers(1100, 1900, F)]
+    base = rng.integers(0, 2**32, (2200, 8), dtype=np.uint32)
+    descs = []
+    for f in range(F):
+        d = base[rng.permutation(2200)[:sizes[f]]].copy()
+        d[:, 5] ^= rng.integers(0, 16, sizes[f]).astype(np.uint32)   # near-duplicates across sets
+        descs.append(d)
+    pl = [(a, b) for a in range(F) for b in range(a + 1, F)]
+    assert len(pl) == 300
+    engine.profile_reset()
+    engine.profile_enable(True)
+    out = _match_dev(engine, descs, pl, 1920)
+    engine.profile_enable(False)
+    n_wide, _ = engine.profile_get("ham_argmin")
+    n_fin, _ = engine.profile_get("match_finish")
+    assert n_fin == 3 and n_wide >= 3 * 2          # three chunks, each with >= 2 wide rounds
+    rounds, evals, evals0 = engine.match_stats()
+    assert rounds >= 2 and evals0 == sum(sizes[a] * sizes[b] for a, b in pl)
+    for m, (a, b) in enumerate(pl):
+        assert _same(out[m][:sizes[a]], cref.match_sorted(descs[a], descs[b])), (a, b)
+
+
+@pytest.mark.parametrize("W,H,F", [(451, 383, 5), (333, 77, 6), (127, 129, 9)])
+def test_detect_batch_odd_frame_sizes(engine, W, H, F):
+    """W*H not a multiple of 4 with F > 1: frame f's base is not 16-byte aligned for f > 0."""
+    assert (W * H) % 4 != 0
+    CAP, radius = 2048, 12
+    pairs = pg.make_brief_pairs(9, 30, 256)
+    dmap = pg.build_dewarp_map(W, H, [3e-4, 1e-7, 0, 0, 0])
+    engine.set_brief_pairs(pairs)
+    engine.set_detect_params(T, radius)
+    engine.set_capacity(1 << 16, CAP)
+    engine.set_dewarp_map(dmap)
+    frames = np.stack([synth.make_frame(W, H, seed=70 + i) for i in range(F)])
+    d_frames = torch.from_numpy(frames).to(DEV)
+    i32 = dict(dtype=torch.int32, device=DEV)
+    d_kp, d_desc = torch.zeros((F, CAP, 4), **i32), torch.zeros((F, CAP, 8), **i32)
+    d_counts, d_nraw = torch.zeros(F, **i32), torch.zeros(F, **i32)
+    torch.cuda.synchronize()
+    engine.detect_batch_dev(d_frames, F, W, H, d_kp, d_desc, d_counts, d_nraw, CAP)
+    engine.check_status()
+    desc = d_desc.cpu().numpy().view(np.uint32)
+    for f in range(F):
+        kept, edesc, n_raw = _oracle_detect(frames[f], dmap, pairs, radius, CAP)
+        n = len(kept)
+        assert int(d_nraw[f]) == n_raw and int(d_counts[f]) == n, f
+        kp = d_kp[f].cpu().numpy()
+        assert (kp[:n, 0] == kept["x"]).all() and (kp[:n, 1] == kept["y"]).all()
+        assert kp[:n, 3].view(np.float32).tobytes() == kept["value"].tobytes()
+        assert (desc[f, :n] == edesc).all()
+    engine.set_dewarp_map(None)
+
+
+def test_survivor_limit_cuts_silently_and_capacity_still_raises(engine):
+    """pgx_set_capacity's max_keypoints_per_frame is a LIMIT (harness-side truncation), the per-call capacity is not."""
+    W, H, radius = 640, 360, 8
+    pairs = pg.make_brief_pairs(2, 30, 256)
+    engine.set_brief_pairs(pairs)
+    engine.set_detect_params(T, radius)
+    engine.set_dewarp_map(None)
+    frame = synth.make_frame(W, H, seed=33, n_shapes=1500)
+    kept, edesc, _ = _oracle_detect(frame, None, pairs, radius, 1 << 20)
+    assert len(kept) > 300
+    engine.set_capacity(1 << 17, 200)
+    kp, desc, _ = engine.detect(frame, capacity=4096)
+    assert len(kp) == 200 and (desc == edesc[:200]).all() and (kp["x"] == kept["x"][:200]).all()
+    engine.set_capacity(1 << 17, 1 << 20)
+    with pytest.raises(pg.CapacityError):
+        engine.detect(frame, capacity=200)
