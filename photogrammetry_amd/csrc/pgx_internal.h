@@ -185,6 +185,7 @@ struct MatchPlan {
     int words;
     int max_n;    // upper bound of any count (<= stride)
     int rounds_mfma;
+    int skip_below = PGX_TAIL_FILL_MAX; // a wide round leaves image pairs alone whose residual (rows and columns) is at most this
 };
 size_t pgx_match_ws_bytes(int M, int stride);
 // wide part (init, whole-chip rounds, tail fill) and per-pair finish of one chunk of image pairs; they may run on
