@@ -254,7 +254,7 @@ def cpu_baseline(frames, dmap, pairs, sample_n):
 # one rank
 # ---------------------------------------------------------------------------------------------------
 
-KERNEL_GROUPS = ("dewarp_gray", "fast", "nms", "brief", "match_init", "ham_argmin", "match_select", "tail_fill", "match_finish")
+KERNEL_GROUPS = ("dewarp_gray", "fast", "nms", "brief", "match_init", "ham_argmin", "match_select", "tail_fill", "tail_rows", "match_finish")
 
 
 def kernel_table(eng, steps):
@@ -357,7 +357,7 @@ def worker(args):
         kern = kernel_table(eng, args.steps)
         rounds_wide, evals, evals0 = eng.match_stats()
         step_ms = dt_max / args.steps * 1e3
-        match_ms = sum(kern[k]["ms_per_step"] for k in ("match_init", "ham_argmin", "match_select", "tail_fill", "match_finish") if k in kern)
+        match_ms = sum(kern[k]["ms_per_step"] for k in ("match_init", "ham_argmin", "match_select", "tail_fill", "tail_rows", "match_finish") if k in kern)
         detect_ms = sum(kern[k]["ms_per_step"] for k in ("dewarp_gray", "fast", "nms", "brief") if k in kern)
         npix = W * H
         n_raw_tot = float(nraw_l.sum())

@@ -28,7 +28,7 @@
 namespace {
 
 constexpr int SEL_NT = 1024;
-constexpr int CNT_N1 = 0, CNT_N2 = 1, CNT_NACC = 2, CNT_N1_ORIG = 3, CNT_N2_ORIG = 4, CNT_PARITY = 5, CNT_FILLED = 6, CNT_WORDS = 8;
+constexpr int CNT_N1 = 0, CNT_N2 = 1, CNT_NACC = 2, CNT_N1_ORIG = 3, CNT_N2_ORIG = 4, CNT_PARITY = 5, CNT_FILLED = 6, CNT_DONE = 7, CNT_WORDS = 8;
 
 struct PairWs {
     uint32_t *rowkey, *colkey, *rows0, *rows1, *cols0, *cols1; // no runtime-indexed arrays: they would live in scratch
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_match_init(uint32_t *ws, const int32_t 
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         p.cnt[CNT_N1] = n1; p.cnt[CNT_N2] = n2; p.cnt[CNT_NACC] = 0;
-        p.cnt[CNT_N1_ORIG] = n1; p.cnt[CNT_N2_ORIG] = n2; p.cnt[CNT_PARITY] = 0; p.cnt[CNT_FILLED] = 0;
+        p.cnt[CNT_N1_ORIG] = n1; p.cnt[CNT_N2_ORIG] = n2; p.cnt[CNT_PARITY] = 0; p.cnt[CNT_FILLED] = 0; p.cnt[CNT_DONE] = 0;
         if (n1 > 0 && n2 == 0) atomicOr(status, (int)PGX_ST_EMPTY_SET); // KeypointMatching.cs:61
     }
 }
@@ -144,14 +144,14 @@ constexpr int VALU_CH = 512; // columns per block in the multi-block kernel
 
 template <int WORDS>
 __global__ __launch_bounds__(256) void k_ham_valu(uint32_t *ws, const uint32_t *__restrict__ desc,
-                                                  const int32_t *__restrict__ pairlist, int S, int words)
+                                                  const int32_t *__restrict__ pairlist, int S, int words, int skip_below)
 {
     extern __shared__ uint32_t lds[];
     const int side = blockIdx.z & 1, m = blockIdx.z >> 1;
     PairWs p = pair_ws(ws, m, S);
     const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2], parity = p.cnt[CNT_PARITY];
     if (n1 <= 0 || n2 <= 0) return;
-    if (n1 <= PGX_TAIL_FILL_MAX && n2 <= PGX_TAIL_FILL_MAX) return; // small enough: the per-pair tail kernel takes it from here
+    if (n1 <= skip_below && n2 <= skip_below) return; // small enough: the per-pair tail kernel takes it from here
     const uint32_t *dA = desc + (size_t)pairlist[2 * m] * S * words;
     const uint32_t *dB = desc + (size_t)pairlist[2 * m + 1] * S * words;
     const int nR = side ? n2 : n1, nC = side ? n1 : n2;
@@ -251,12 +251,12 @@ __device__ void select_compact_wg(PairWs p, int parity, uint32_t *wsum)
     __syncthreads();
 }
 
-__global__ __launch_bounds__(SEL_NT) void k_match_select(uint32_t *ws, int S, unsigned long long *evals)
+__global__ __launch_bounds__(SEL_NT) void k_match_select(uint32_t *ws, int S, unsigned long long *evals, int skip_below)
 {
     __shared__ uint32_t wsum[SEL_NT / 64];
     PairWs p = pair_ws(ws, blockIdx.x, S);
     if (p.cnt[CNT_N1] <= 0 || p.cnt[CNT_N2] <= 0) return;
-    if (p.cnt[CNT_N1] <= PGX_TAIL_FILL_MAX && p.cnt[CNT_N2] <= PGX_TAIL_FILL_MAX) return; // round was skipped
+    if (p.cnt[CNT_N1] <= skip_below && p.cnt[CNT_N2] <= skip_below) return; // round was skipped
     const int parity = p.cnt[CNT_PARITY];
     if (threadIdx.x == 0) atomicAdd(evals, (unsigned long long)p.cnt[CNT_N1] * (unsigned long long)p.cnt[CNT_N2]);
     select_compact_wg(p, parity, wsum);
@@ -561,6 +561,7 @@ __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uin
     __shared__ uint32_t wsum[SEL_NT / 64];
     const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     PairWs p = pair_ws(ws, m, S);
+    if (p.cnt[CNT_DONE]) return; // finished by k_match_tail
     int parity = p.cnt[CNT_PARITY];
     const uint32_t *dA = desc + (size_t)pairlist[2 * m] * S * words;
     const uint32_t *dB = desc + (size_t)pairlist[2 * m + 1] * S * words;
@@ -608,6 +609,7 @@ __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uin
 
 } // namespace
 
+#include "k_match_tail.inc"
 #include "k_match_mfma.inc"
 
 size_t pgx_match_ws_bytes(int M, int stride) { return (size_t)M * pair_ws_words(stride) * 4; }
@@ -619,7 +621,7 @@ static void launch_rounds_valu(hipStream_t s, uint32_t *ws, const uint32_t *desc
     const int W = WORDS > 0 ? WORDS : plan.words;
     dim3 grid((plan.max_n + 255) / 256, (plan.max_n + VALU_CH - 1) / VALU_CH, plan.M * 2);
     const size_t shm = (size_t)256 * (W + 1) * 4;
-    hipLaunchKernelGGL((k_ham_valu<WORDS>), grid, dim3(256), shm, s, ws, desc, pairlist, plan.stride, plan.words);
+    hipLaunchKernelGGL((k_ham_valu<WORDS>), grid, dim3(256), shm, s, ws, desc, pairlist, plan.stride, plan.words, plan.skip_below);
 }
 
 template <int WORDS>
@@ -665,12 +667,19 @@ void pgx_launch_match_wide(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, 
         {
             ProfScope ps(ctx, "match_select", s);
             hipLaunchKernelGGL(k_match_select, dim3(plan.M), dim3(SEL_NT), 0, s, ws, plan.stride,
-                               reinterpret_cast<unsigned long long *>(status + 4) + (r < PGX_MAX_WIDE_ROUNDS ? r : PGX_MAX_WIDE_ROUNDS - 1));
+                               reinterpret_cast<unsigned long long *>(status + 4) + (r < PGX_MAX_WIDE_ROUNDS ? r : PGX_MAX_WIDE_ROUNDS - 1), plan.skip_below);
         }
     }
     if (plan.words == 8) {
-        ProfScope ps(ctx, "tail_fill", s);
-        hipLaunchKernelGGL(k_tail_fill, dim3(PGX_TAIL_MAX / 16, 2, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
+        ProfScope ps(ctx, "tail_rows", s);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)tail_rows_lds_bytes());
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_tail_rows, dim3(PGX_TAIL_MAX / TF_ROWS, plan.M), dim3(TF_NT), tail_rows_lds_bytes(), s, ws, d_desc,
+                           d_pairlist, plan.stride);
     }
 }
 
@@ -680,6 +689,11 @@ void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc
     if (plan.M <= 0) return;
     uint32_t *ws = reinterpret_cast<uint32_t *>(wsv);
     ProfScope ps(ctx, "match_finish", s);
-    if (plan.words == 8) launch_finish<8>(s, ws, d_desc, d_pairlist, plan, d_out, status);
-    else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out, status);
+    if (plan.words == 8) {
+        const size_t n2p = pow2_ge((size_t)(plan.max_n > 1 ? plan.max_n : 1));
+        const size_t key_cap = n2p <= 8192 ? n2p : 0; // sort keys in LDS up to 32 KiB, else in the workspace
+        hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(GS_NT), key_cap * 4, s, ws, d_desc, d_pairlist, plan.stride, d_out,
+                           (uint32_t)key_cap, status);
+        launch_finish<8>(s, ws, d_desc, d_pairlist, plan, d_out, status); // only pairs k_match_gs declined (residual too large, or a distance of 256)
+    } else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out, status);
 }

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <new>
 #include <cstring>
+#include <cstdlib>
 
 #define PGX_VERSION_STR "pgx 0.1 (gfx950)"
 
@@ -129,20 +130,37 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     // all-CU rounds until the residual fits the LDS tail (random data halves per round; each launch
     // skips image pairs that already fit, so extra rounds only cost their launch)
     plan.rounds_mfma = 0;
-    for (int n = plan.max_n; n > PGX_TAIL_FILL_MAX && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
+    // 256-bit descriptors: the whole-chip k_tail_fill caches residuals up to PGX_TAIL_MAX, so wide rounds stop there;
+    // other lengths: the tail workgroup stages the descriptors itself (PGX_TAIL_FILL_MAX)
+    plan.skip_below = words == 8 ? PGX_TAIL_MAX : PGX_TAIL_FILL_MAX;
+    {
+        static const int ovr = [] { const char *e = getenv("PGX_SKIP_BELOW"); return e ? atoi(e) : 0; }(); // developer A/B switch
+        if (ovr > 0 && ovr <= PGX_TAIL_MAX && words == 8) plan.skip_below = ovr;
+    }
+    for (int n = plan.max_n; n > plan.skip_below && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
     if (plan.rounds_mfma > 0 && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS) plan.rounds_mfma++;
     HIPCHK(c, hipMemsetAsync(c->d_status + 4, 0, PGX_MAX_WIDE_ROUNDS * 8, c->stream));
-    if (M <= CHUNK) { // one chunk: everything in order on the context's stream
-        plan.M = M;
-        pgx_launch_match_wide(c, c->stream, d_desc, d_counts, d_pairlist, plan, c->ws_match.p, c->d_status);
-        pgx_launch_match_finish(c, c->stream, d_desc, d_pairlist, plan, c->ws_match.p, d_out, c->d_status);
+    static const bool overlap = [] { const char *e = getenv("PGX_MATCH_OVERLAP"); return !(e && e[0] == '0'); }(); // developer A/B switch
+    if (M <= CHUNK || !overlap) { // everything in order on the context's stream
+        for (int m0 = 0; m0 < M; m0 += CHUNK) {
+            plan.M = (M - m0 < CHUNK) ? M - m0 : CHUNK;
+            pgx_launch_match_wide(c, c->stream, d_desc, d_counts, d_pairlist + 2 * (size_t)m0, plan, c->ws_match.p, c->d_status);
+            pgx_launch_match_finish(c, c->stream, d_desc, d_pairlist + 2 * (size_t)m0, plan, c->ws_match.p, d_out + (size_t)m0 * stride, c->d_status);
+        }
     } else {
         // Several chunks: the per-pair finish is a latency-bound chain on one workgroup per image pair (a quarter of
         // the chip at 128 pairs), so the finish of chunk i runs on a second stream beside the whole-chip rounds of
         // chunk i + 1.  Two workspaces alternate; events order "inputs ready -> wide(i) -> finish(i) -> wide(i + 2)".
         HIPCHK(c, c->ws_match2.ensure(pgx_match_ws_bytes(mc, stride)));
         for (int k = 0; k < 2; k++) {
-            if (!c->mstream[k]) HIPCHK(c, hipStreamCreateWithFlags(&c->mstream[k], hipStreamNonBlocking));
+            if (!c->mstream[k]) {
+                // The finish stream gets the highest priority: streams of one priority class share a small pool of
+                // hardware queues (4 by default) round-robin, and two streams on one queue run strictly in order; a
+                // priority class of its own gives the finishes their own queue and first call on freed CU slots.
+                int lo = 0, hi = 0;
+                HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+                HIPCHK(c, hipStreamCreateWithPriority(&c->mstream[k], hipStreamNonBlocking, k == 1 ? hi : lo));
+            }
             if (!c->ev_wide[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_wide[k], hipEventDisableTiming));
             if (!c->ev_fin[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fin[k], hipEventDisableTiming));
             if (!c->ev_join[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));

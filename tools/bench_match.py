@@ -51,7 +51,7 @@ def main():
     ms = (time.perf_counter() - t0) * 1e3 / args.steps
     eng.profile_enable(False)
     kern = {}
-    for name in ("match_init", "ham_argmin", "match_select", "tail_fill", "match_finish"):
+    for name in ("match_init", "ham_argmin", "match_select", "tail_fill", "tail_rows", "match_finish"):
         n, t = eng.profile_get(name)
         if n:
             kern[name] = round(t / args.steps, 4)
