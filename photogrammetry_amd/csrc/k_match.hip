@@ -670,17 +670,22 @@ void pgx_launch_match_wide(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, 
                                reinterpret_cast<unsigned long long *>(status + 4) + (r < PGX_MAX_WIDE_ROUNDS ? r : PGX_MAX_WIDE_ROUNDS - 1), plan.skip_below);
         }
     }
-    if (plan.words == 8) {
-        ProfScope ps(ctx, "tail_rows", s);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)tail_rows_lds_bytes());
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(k_tail_rows, dim3(PGX_TAIL_MAX / TF_ROWS, plan.M), dim3(TF_NT), tail_rows_lds_bytes(), s, ws, d_desc,
-                           d_pairlist, plan.stride);
+}
+
+void pgx_launch_match_rows(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_pairlist,
+                           const MatchPlan &plan, void *wsv, int *status)
+{
+    if (plan.M <= 0 || plan.words != 8) return;
+    uint32_t *ws = reinterpret_cast<uint32_t *>(wsv);
+    ProfScope ps(ctx, "tail_rows", s);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)tail_rows_lds_bytes());
+        attr_set = true;
     }
+    hipLaunchKernelGGL(k_tail_rows, dim3(PGX_TAIL_MAX / TF_ROWS, plan.M), dim3(TF_NT), tail_rows_lds_bytes(), s, ws, d_desc,
+                       d_pairlist, plan.stride);
 }
 
 void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_pairlist,

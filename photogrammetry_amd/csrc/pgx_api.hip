@@ -123,14 +123,14 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     // image pairs go through in chunks so the per-pair workspace (incl. the tail's 16 MiB distance cache) stays bounded
     const int CHUNK = 128;
     const int mc = M < CHUNK ? M : CHUNK;
-    HIPCHK(c, c->ws_match.ensure(pgx_match_ws_bytes(mc, stride)));
+    HIPCHK(c, c->ws_matchn[0].ensure(pgx_match_ws_bytes(mc, stride)));
     MatchPlan plan;
     plan.stride = stride; plan.words = words;
     plan.max_n = max_n > stride ? stride : (max_n < 1 ? 1 : max_n);
-    // all-CU rounds until the residual fits the LDS tail (random data halves per round; each launch
+    // all-CU rounds until the residual fits the per-pair tail (random data halves per round; each launch
     // skips image pairs that already fit, so extra rounds only cost their launch)
     plan.rounds_mfma = 0;
-    // 256-bit descriptors: the whole-chip k_tail_fill caches residuals up to PGX_TAIL_MAX, so wide rounds stop there;
+    // 256-bit descriptors: k_tail_rows caches the residual's distance rows up to PGX_TAIL_MAX, so wide rounds stop there;
     // other lengths: the tail workgroup stages the descriptors itself (PGX_TAIL_FILL_MAX)
     plan.skip_below = words == 8 ? PGX_TAIL_MAX : PGX_TAIL_FILL_MAX;
     {
@@ -144,48 +144,56 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     if (M <= CHUNK || !overlap) { // everything in order on the context's stream
         for (int m0 = 0; m0 < M; m0 += CHUNK) {
             plan.M = (M - m0 < CHUNK) ? M - m0 : CHUNK;
-            pgx_launch_match_wide(c, c->stream, d_desc, d_counts, d_pairlist + 2 * (size_t)m0, plan, c->ws_match.p, c->d_status);
-            pgx_launch_match_finish(c, c->stream, d_desc, d_pairlist + 2 * (size_t)m0, plan, c->ws_match.p, d_out + (size_t)m0 * stride, c->d_status);
+            const int32_t *pl = d_pairlist + 2 * (size_t)m0;
+            pgx_launch_match_wide(c, c->stream, d_desc, d_counts, pl, plan, c->ws_matchn[0].p, c->d_status);
+            pgx_launch_match_rows(c, c->stream, d_desc, pl, plan, c->ws_matchn[0].p, c->d_status);
+            pgx_launch_match_finish(c, c->stream, d_desc, pl, plan, c->ws_matchn[0].p, d_out + (size_t)m0 * stride, c->d_status);
         }
     } else {
-        // Several chunks: the per-pair finish is a latency-bound chain on one workgroup per image pair (a quarter of
-        // the chip at 128 pairs), so the finish of chunk i runs on a second stream beside the whole-chip rounds of
-        // chunk i + 1.  Two workspaces alternate; events order "inputs ready -> wide(i) -> finish(i) -> wide(i + 2)".
-        HIPCHK(c, c->ws_match2.ensure(pgx_match_ws_bytes(mc, stride)));
-        for (int k = 0; k < 2; k++) {
+        // Several chunks: a three-stage pipeline over chunks on three streams -- the whole-chip mutual-nearest rounds
+        // (matrix pipe) of chunk i + 2 beside the residual distance rows (vector ALU) of chunk i + 1 beside the per-pair
+        // finish (latency-bound, one small workgroup per pair) of chunk i.  Three workspaces rotate; events order
+        // "inputs ready -> wide(i) -> rows(i) -> finish(i) -> wide(i + 3)".  Each stream sits in a stream-priority class
+        // of its own where the device has three: streams of one class share a small pool of hardware queues round-robin,
+        // and two streams on one queue run strictly in order.
+        const int NS = 3;
+        int lo = 0, hi = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi)); // lo = least priority (numerically greatest)
+        for (int k = 0; k < NS; k++) {
+            HIPCHK(c, c->ws_matchn[k].ensure(pgx_match_ws_bytes(mc, stride)));
             if (!c->mstream[k]) {
-                // The finish stream gets the highest priority: streams of one priority class share a small pool of
-                // hardware queues (4 by default) round-robin, and two streams on one queue run strictly in order; a
-                // priority class of its own gives the finishes their own queue and first call on freed CU slots.
-                int lo = 0, hi = 0;
-                HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-                HIPCHK(c, hipStreamCreateWithPriority(&c->mstream[k], hipStreamNonBlocking, k == 1 ? hi : lo));
+                const int prio = k == 0 ? lo : (k == 2 ? hi : (lo + hi) / 2);
+                HIPCHK(c, hipStreamCreateWithPriority(&c->mstream[k], hipStreamNonBlocking, prio));
             }
             if (!c->ev_wide[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_wide[k], hipEventDisableTiming));
+            if (!c->ev_rows[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rows[k], hipEventDisableTiming));
             if (!c->ev_fin[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fin[k], hipEventDisableTiming));
             if (!c->ev_join[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
         }
         if (!c->ev_in) HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-        hipStream_t sw = c->mstream[0], sf = c->mstream[1];
+        hipStream_t sw = c->mstream[0], sr = c->mstream[1], sf = c->mstream[2];
         HIPCHK(c, hipEventRecord(c->ev_in, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(sw, c->ev_in, 0));
-        HIPCHK(c, hipStreamWaitEvent(sf, c->ev_in, 0));
+        for (int k = 0; k < NS; k++) HIPCHK(c, hipStreamWaitEvent(c->mstream[k], c->ev_in, 0));
         int i = 0;
         for (int m0 = 0; m0 < M; m0 += CHUNK, i++) {
-            const int b = i & 1;
-            void *ws = b ? c->ws_match2.p : c->ws_match.p;
+            const int b = i % NS;
+            void *ws = c->ws_matchn[b].p;
+            const int32_t *pl = d_pairlist + 2 * (size_t)m0;
             plan.M = (M - m0 < CHUNK) ? M - m0 : CHUNK;
-            if (i >= 2) HIPCHK(c, hipStreamWaitEvent(sw, c->ev_fin[b], 0)); // this workspace's previous chunk is finished
-            pgx_launch_match_wide(c, sw, d_desc, d_counts, d_pairlist + 2 * (size_t)m0, plan, ws, c->d_status);
+            if (i >= NS) HIPCHK(c, hipStreamWaitEvent(sw, c->ev_fin[b], 0)); // this workspace's previous chunk is finished
+            pgx_launch_match_wide(c, sw, d_desc, d_counts, pl, plan, ws, c->d_status);
             HIPCHK(c, hipEventRecord(c->ev_wide[b], sw));
-            HIPCHK(c, hipStreamWaitEvent(sf, c->ev_wide[b], 0));
-            pgx_launch_match_finish(c, sf, d_desc, d_pairlist + 2 * (size_t)m0, plan, ws, d_out + (size_t)m0 * stride, c->d_status);
+            HIPCHK(c, hipStreamWaitEvent(sr, c->ev_wide[b], 0));
+            pgx_launch_match_rows(c, sr, d_desc, pl, plan, ws, c->d_status);
+            HIPCHK(c, hipEventRecord(c->ev_rows[b], sr));
+            HIPCHK(c, hipStreamWaitEvent(sf, c->ev_rows[b], 0));
+            pgx_launch_match_finish(c, sf, d_desc, pl, plan, ws, d_out + (size_t)m0 * stride, c->d_status);
             HIPCHK(c, hipEventRecord(c->ev_fin[b], sf));
         }
-        HIPCHK(c, hipEventRecord(c->ev_join[0], sw));
-        HIPCHK(c, hipEventRecord(c->ev_join[1], sf));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[0], 0));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[1], 0));
+        for (int k = 0; k < NS; k++) {
+            HIPCHK(c, hipEventRecord(c->ev_join[k], c->mstream[k]));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[k], 0));
+        }
     }
     c->last_rounds_mfma = plan.rounds_mfma;
     HIPCHK(c, hipGetLastError());
@@ -235,13 +243,14 @@ void pgx_ctx_destroy(pgx_ctx *c)
         for (auto &ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     DevBuf *bufs[] = {&c->d_pairs, &c->d_map, &c->ws_gray, &c->ws_seg, &c->ws_segoff, &c->ws_nraw, &c->ws_rawxy,
                       &c->ws_rawscore, &c->ws_nms, &c->ws_order, &c->ws_nkept, &c->st_a, &c->st_b, &c->st_c,
-                      &c->st_d, &c->st_e, &c->st_f, &c->ws_match, &c->ws_match2};
+                      &c->st_d, &c->st_e, &c->st_f, &c->ws_matchn[0], &c->ws_matchn[1], &c->ws_matchn[2]};
     for (DevBuf *b : bufs) b->release();
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 3; k++) {
         if (c->mstream[k]) (void)hipStreamDestroy(c->mstream[k]);
         if (c->ev_wide[k]) (void)hipEventDestroy(c->ev_wide[k]);
+        if (c->ev_rows[k]) (void)hipEventDestroy(c->ev_rows[k]);
         if (c->ev_fin[k]) (void)hipEventDestroy(c->ev_fin[k]);
         if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
     }

@@ -7,6 +7,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -80,11 +81,11 @@ struct pgx_ctx {
     DevBuf ws_gray, ws_seg, ws_segoff, ws_nraw, ws_rawxy, ws_rawscore, ws_nms, ws_order, ws_nkept;
     // host-API staging
     DevBuf st_a, st_b, st_c, st_d, st_e, st_f;
-    // match workspaces: two, so that with more than one chunk of image pairs the per-pair finish of chunk i runs
-    // (on its own stream) beside the wide rounds of chunk i + 1
-    DevBuf ws_match, ws_match2;
-    hipStream_t mstream[2] = {nullptr, nullptr}; // [0] wide rounds, [1] finishes (created on first use)
-    hipEvent_t ev_in = nullptr, ev_wide[2] = {nullptr, nullptr}, ev_fin[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+    // match workspaces: three, so that with several chunks of image pairs the stages of consecutive chunks run side by side
+    DevBuf ws_matchn[3];
+    hipStream_t mstream[3] = {nullptr, nullptr, nullptr}; // [0] wide rounds, [1] residual distance rows, [2] per-pair finishes
+    hipEvent_t ev_in = nullptr, ev_wide[3] = {nullptr, nullptr, nullptr}, ev_rows[3] = {nullptr, nullptr, nullptr},
+               ev_fin[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
 
     // profiling
     bool prof_on = false;
@@ -188,9 +189,11 @@ struct MatchPlan {
     int skip_below = PGX_TAIL_FILL_MAX; // a wide round leaves image pairs alone whose residual (rows and columns) is at most this
 };
 size_t pgx_match_ws_bytes(int M, int stride);
-// wide part (init, whole-chip rounds, tail fill) and per-pair finish of one chunk of image pairs; they may run on
-// different streams (the caller orders them with an event)
+// the three stages of one chunk of image pairs -- wide part (init, whole-chip mutual-nearest rounds), residual distance
+// rows (256-bit descriptors only), per-pair finish; they may run on different streams (the caller orders them with events)
 void pgx_launch_match_wide(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_counts,
                            const int32_t *d_pairlist, const MatchPlan &plan, void *ws, int *status);
+void pgx_launch_match_rows(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_pairlist,
+                           const MatchPlan &plan, void *ws, int *status);
 void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_pairlist,
                              const MatchPlan &plan, void *ws, pgx_pair *d_out, int *status);
