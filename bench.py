@@ -351,6 +351,36 @@ def worker(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t[0].item())
 
+    # N > 1: the same job once more through the C ABI's own communicator (pgx_comm_init / pgx_sequence_step_dev: what a
+    # non-Python host would call) -- results must equal the torch.distributed run; informative, never `value`
+    c_abi = None
+    if world > 1:
+        try:
+            box = [pg.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            eng.comm_init(rank, world, box[0])
+            job2 = pdist.ShardedSequence(eng, W, H, n_frames, pair_list, NKP, WORDS, dev, stream=stream, comm="pgx")
+            job2.step(d_frames)
+            eng.check_status()
+            same = bool(torch.equal(job2.out_all, job.out_all) and torch.equal(job2.counts_all, job.counts_all))
+            k2 = max(3, min(20, args.steps))
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(k2):
+                job2.step(d_frames)
+            barrier()
+            t2 = torch.tensor([(time.perf_counter() - t0) / k2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            eng.check_status()
+            c_abi = {"ms_per_step": float(t2[0].item()) * 1e3, "steps": k2, "equal_to_torch_distributed_run": same,
+                     "value": pairs_per_step / float(t2[0].item()),
+                     "what": "the same job as ONE C call per step (pgx_sequence_step_dev) on the context's own RCCL communicator"}
+            del job2
+            eng.comm_destroy()
+        except Exception as e:   # informative leg: never lose the headline line to it
+            log("[rank %d] C-ABI communicator leg failed: %r" % (rank, e))
+            c_abi = {"error": repr(e)}
+
     rc = 0
     if rank == 0:
         F_l, M_l = len(job.my_frames), len(job.my_pairs)
@@ -413,7 +443,7 @@ def worker(args):
                                          "achieved": byts / (detect_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                          "frac": byts / (detect_ms * 1e-3) / HBM_PEAK, "traffic": None,
                                          "algorithmic": "SURVEY 8d: 24 B/pixel for the fused-minimum detect stream x %d frames" % F_l}
-        dominant = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
+        dominant = max((k for k in kern if k in rooflines), key=lambda k: kern[k]["ms_per_step"], default=None)
         result = {
             "metric": "descriptor pairs matched/sec", "value": pairs_per_step * args.steps / dt_max,
             "unit": "descriptor pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -432,6 +462,7 @@ def worker(args):
                                       % (world, world, "" if world > 1 else " (elided at N = 1)")},
             "roofline": rooflines.get(dominant),
             "mfma": mfma,
+            "c_abi_comm": c_abi,
             "traffic_note": traffic_src,
             "rooflines": rooflines,
             "kernels": kern,

@@ -26,6 +26,7 @@
 #ifndef PGX_H
 #define PGX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -40,6 +41,7 @@ extern "C" {
 #define PGX_E_BADARG         5  /* ArgumentException / null pointer / unsupported size    */
 #define PGX_E_HIP            6  /* a HIP runtime call failed                              */
 #define PGX_E_NOT_CONFIGURED 7  /* stage used before its pgx_set_* call                   */
+#define PGX_E_RCCL           8  /* an RCCL call failed, or librccl could not be loaded    */
 
 #define PGX_DIST_NONE 2147483647 /* int.MaxValue: tail entries when N1 > N2 (KeypointMatching.cs:40-42) */
 
@@ -135,6 +137,32 @@ int pgx_detect_batch_dev(pgx_ctx *ctx, const uint16_t *d_rgba64, int F, int W, i
 int pgx_match_batch_dev(pgx_ctx *ctx, const uint32_t *d_desc, const int32_t *d_counts,
                         int stride, int words, const int32_t *d_pairlist, int M, int max_count,
                         pgx_pair *d_out);
+
+/* ---- multi-GPU: one process and one context per GPU; the context owns the RCCL communicator -------- */
+/* The reference handles one image pair in one process (TestService.cs:80-96) and nothing couples image pairs, so the
+ * path shards with no collective inside detect or match: frame f -> rank f mod G, image pair p -> rank p mod G, and two
+ * exchanges of FIXED-SIZE records (per-frame {count, descriptors}; per-pair match lists -- always exactly N1 entries,
+ * KeypointMatching.cs:38), both in-place all-gathers over a rank-major buffer [G][slots][...]: global item k sits in
+ * block k mod G at place k / G.  librccl is loaded on first use; without it these calls return PGX_E_RCCL. */
+#define PGX_COMM_ID_BYTES 128
+/* Rank 0 makes the id (ncclGetUniqueId); the host hands the 128 bytes to every rank (socket, file, MPI, ...). */
+int pgx_comm_unique_id(void *id_out /* [PGX_COMM_ID_BYTES] */);
+/* Collective over all ranks (ncclCommInitRank on the context's device). */
+int pgx_comm_init(pgx_ctx *ctx, int rank, int world, const void *id /* [PGX_COMM_ID_BYTES] */);
+int pgx_comm_destroy(pgx_ctx *ctx);
+int pgx_comm_info(pgx_ctx *ctx, int *rank, int *world);   /* (0, 1) without a communicator */
+/* In-place all-gather on the context's stream: this rank's record is bytes [rank * bytes_per_rank, +bytes_per_rank) of
+ * d_buf [world * bytes_per_rank].  world == 1: no-op. */
+int pgx_allgather_dev(pgx_ctx *ctx, void *d_buf, size_t bytes_per_rank);
+/* The four phases of one job, enqueued on the context's stream: detect this rank's n_local_frames frames into its block
+ * of d_desc_all [world * frame_slots][capacity][words] / d_counts_all [world * frame_slots]; all-gather both; match this
+ * rank's n_local_pairs image pairs (d_pairlist_local [n][2] = SLOT indices into the gathered buffers) into its block of
+ * d_out_all [world * pair_slots][capacity]; all-gather the lists.  Lists are cut to `capacity` by pgx_set_capacity's
+ * survivor limit (set it <= capacity).  world == 1: the same without the collectives. */
+int pgx_sequence_step_dev(pgx_ctx *ctx, const uint16_t *d_frames_local, int n_local_frames, int frame_slots, int W, int H,
+                          pgx_keypoint *d_kp_local, uint32_t *d_desc_all, int32_t *d_counts_all, int32_t *d_nraw_local,
+                          int capacity, const int32_t *d_pairlist_local, int n_local_pairs, int pair_slots,
+                          pgx_pair *d_out_all);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------- */
 /* When on, the named hot kernels are bracketed by HIP events on the launch stream. */

@@ -47,6 +47,13 @@ _EXC = {PGX_E_DIM_MISMATCH: ArgumentException, PGX_E_BADARG: ArgumentException,
         PGX_E_CAPACITY: CapacityError}
 
 
+class RcclError(PgxError):
+    pass
+
+
+_EXC[_lib.PGX_E_RCCL] = RcclError
+
+
 def _ptr(a):
     return C.c_void_p(a.ctypes.data) if a is not None else None
 
@@ -186,6 +193,32 @@ class Engine:
                                               _dptr(d_pairlist), int(M),
                                               int(stride if max_count is None else max_count), _dptr(d_out)))
 
+    # -- multi-GPU: the context's own RCCL communicator (pgx_comm_*) ------------------------------
+    def comm_init(self, rank, world, unique_id):
+        """Collective: every rank calls this with the 128 bytes rank 0 got from comm_unique_id()."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(self._L.pgx_comm_init(self._h, int(rank), int(world), buf))
+
+    def comm_destroy(self):
+        self._chk(self._L.pgx_comm_destroy(self._h))
+
+    def comm_info(self):
+        r, w = C.c_int(0), C.c_int(0)
+        self._chk(self._L.pgx_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def allgather_dev(self, d_buf, bytes_per_rank):
+        """In-place all-gather of fixed-size records on the context's stream (rank-major buffer)."""
+        self._chk(self._L.pgx_allgather_dev(self._h, _dptr(d_buf), C.c_size_t(int(bytes_per_rank))))
+
+    def sequence_step_dev(self, d_frames_local, n_local_frames, frame_slots, W, H, d_kp_local, d_desc_all, d_counts_all,
+                          d_nraw_local, capacity, d_pairlist_local, n_local_pairs, pair_slots, d_out_all):
+        """The four phases of one sharded job (detect -> all-gather -> match -> all-gather) in one C call."""
+        self._chk(self._L.pgx_sequence_step_dev(self._h, _dptr(d_frames_local), int(n_local_frames), int(frame_slots), int(W), int(H),
+                                                _dptr(d_kp_local), _dptr(d_desc_all), _dptr(d_counts_all), _dptr(d_nraw_local),
+                                                int(capacity), _dptr(d_pairlist_local), int(n_local_pairs), int(pair_slots),
+                                                _dptr(d_out_all)))
+
     def debug_counters(self):
         out = np.zeros(8, dtype=np.int32)
         self._chk(self._L.pgx_debug_counters(self._h, _ptr(out)))
@@ -207,6 +240,15 @@ class Engine:
         n, ms = C.c_int(0), C.c_double(0.0)
         self._chk(self._L.pgx_profile_get(self._h, name.encode(), C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+
+def comm_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 makes them, the host hands them to every rank)."""
+    buf = (C.c_char * 128)()
+    rc = _lib.lib().pgx_comm_unique_id(buf)
+    if rc != PGX_OK:
+        raise PgxError(rc, "pgx_comm_unique_id: librccl could not be loaded or ncclGetUniqueId failed")
+    return bytes(buf)
 
 
 def make_brief_pairs(seed, sigma, P):

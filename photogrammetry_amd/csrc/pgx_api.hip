@@ -202,6 +202,18 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
 
 } // namespace
 
+// used by pgx_comm.hip (the caller holds the context's mutex)
+int pgx_enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_keypoint *d_kp, uint32_t *d_desc,
+                       int32_t *d_counts, int32_t *d_nraw, int cap)
+{
+    return enqueue_detect(c, d_rgba, F, W, H, d_kp, d_desc, d_counts, d_nraw, cap);
+}
+int pgx_enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, int stride, int words,
+                      const int32_t *d_pairlist, int M, int max_n, pgx_pair *d_out)
+{
+    return enqueue_match(c, d_desc, d_counts, stride, words, d_pairlist, M, max_n, d_out);
+}
+
 extern "C" {
 
 const char *pgx_version(void) { return PGX_VERSION_STR; }
@@ -239,6 +251,7 @@ void pgx_ctx_destroy(pgx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)pgx_comm_destroy(c);
     for (auto &kv : c->prof)
         for (auto &ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     DevBuf *bufs[] = {&c->d_pairs, &c->d_map, &c->ws_gray, &c->ws_seg, &c->ws_segoff, &c->ws_nraw, &c->ws_rawxy,

@@ -1,0 +1,170 @@
+// pgx_comm.hip -- multi-GPU part of the C ABI ("ctx owns the RCCL comm", PGX_E_RCCL).
+//
+// One process per GPU, one context per process.  The path needs exactly two exchanges per job, both all-gathers of
+// fixed-size records (per-frame {count, descriptors}; per-image-pair match lists: the reference always emits exactly N1
+// entries, KeypointMatching.cs:38), so the ABI offers an in-place all-gather on the context's stream and the four-phase
+// step built from it.  RCCL is loaded at run time (dlopen) so that libpgx.so itself has no link-time dependency: a
+// single-GPU host never touches it, and a missing library surfaces as PGX_E_RCCL from pgx_comm_init, nowhere else.
+#include "pgx_internal.h"
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+// the slice of rccl.h this file needs (ABI-stable NCCL entry points)
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+enum { ncclSuccessV = 0, ncclUint8V = 1 };
+
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.h) break;
+        }
+        if (!r.h) { r.err = std::string("dlopen(librccl.so.1) failed: ") + (dlerror() ? dlerror() : "?"); return; }
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.h, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.h, "ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.h, "ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.h, "ncclAllGather"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.h, "ncclGetErrorString"));
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) r.err = "librccl lacks an expected nccl* symbol";
+    });
+    return &r;
+}
+
+int comm_fail(pgx_ctx *c, const char *what, ncclResult_t rc)
+{
+    Rccl *r = rccl();
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, (r->GetErrorString && rc) ? r->GetErrorString(rc) : (r->err.empty() ? "RCCL error" : r->err.c_str()));
+    if (c) c->err = buf;
+    return PGX_E_RCCL;
+}
+
+} // namespace
+
+int pgx_enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_keypoint *d_kp, uint32_t *d_desc,
+                       int32_t *d_counts, int32_t *d_nraw, int cap);
+int pgx_enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, int stride, int words,
+                      const int32_t *d_pairlist, int M, int max_n, pgx_pair *d_out);
+
+extern "C" {
+
+int pgx_comm_unique_id(void *id_out)
+{
+    if (!id_out) return PGX_E_BADARG;
+    Rccl *r = rccl();
+    if (!r->err.empty()) return PGX_E_RCCL;
+    ncclUniqueId id;
+    if (r->GetUniqueId(&id) != ncclSuccessV) return PGX_E_RCCL;
+    memcpy(id_out, &id, sizeof id);
+    return PGX_OK;
+}
+
+int pgx_comm_init(pgx_ctx *c, int rank, int world, const void *id)
+{
+    if (!c || !id || world < 1 || rank < 0 || rank >= world) return c ? (c->err = "bad rank/world", PGX_E_BADARG) : PGX_E_BADARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    (void)hipSetDevice(c->device);
+    if (c->comm) { c->err = "communicator already initialised"; return PGX_E_BADARG; }
+    Rccl *r = rccl();
+    if (!r->err.empty()) return comm_fail(c, "pgx_comm_init", 0);
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t rc = r->CommInitRank(&comm, world, uid, rank);
+    if (rc != ncclSuccessV) return comm_fail(c, "ncclCommInitRank", rc);
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return PGX_OK;
+}
+
+int pgx_comm_destroy(pgx_ctx *c)
+{
+    if (!c) return PGX_E_BADARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->comm) return PGX_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    const ncclResult_t rc = rccl()->CommDestroy(reinterpret_cast<ncclComm_t>(c->comm));
+    c->comm = nullptr;
+    c->comm_rank = 0;
+    c->comm_world = 1;
+    return rc == ncclSuccessV ? PGX_OK : comm_fail(c, "ncclCommDestroy", rc);
+}
+
+int pgx_comm_info(pgx_ctx *c, int *rank, int *world)
+{
+    if (!c) return PGX_E_BADARG;
+    if (rank) *rank = c->comm_rank;
+    if (world) *world = c->comm_world;
+    return PGX_OK;
+}
+
+static int allgather_locked(pgx_ctx *c, void *d_buf, size_t bytes_per_rank)
+{
+    if (c->comm_world <= 1 || bytes_per_rank == 0) return PGX_OK; // one rank: the buffer already is the gathered one
+    if (!c->comm) { c->err = "pgx_comm_init not called"; return PGX_E_NOT_CONFIGURED; }
+    const char *send = reinterpret_cast<const char *>(d_buf) + (size_t)c->comm_rank * bytes_per_rank; // in place
+    const ncclResult_t rc = rccl()->AllGather(send, d_buf, bytes_per_rank, ncclUint8V, reinterpret_cast<ncclComm_t>(c->comm), c->stream);
+    return rc == ncclSuccessV ? PGX_OK : comm_fail(c, "ncclAllGather", rc);
+}
+
+int pgx_allgather_dev(pgx_ctx *c, void *d_buf, size_t bytes_per_rank)
+{
+    if (!c || !d_buf) return PGX_E_BADARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    (void)hipSetDevice(c->device);
+    return allgather_locked(c, d_buf, bytes_per_rank);
+}
+
+int pgx_sequence_step_dev(pgx_ctx *c, const uint16_t *d_frames_local, int n_local_frames, int frame_slots, int W, int H,
+                          pgx_keypoint *d_kp_local, uint32_t *d_desc_all, int32_t *d_counts_all, int32_t *d_nraw_local,
+                          int capacity, const int32_t *d_pairlist_local, int n_local_pairs, int pair_slots,
+                          pgx_pair *d_out_all)
+{
+    if (!c || !d_desc_all || !d_counts_all || !d_out_all || capacity <= 0 || frame_slots < 0 || pair_slots < 0 ||
+        n_local_frames < 0 || n_local_frames > frame_slots || n_local_pairs < 0 || n_local_pairs > pair_slots ||
+        (n_local_frames > 0 && (!d_frames_local || !d_kp_local || !d_nraw_local)) || (n_local_pairs > 0 && !d_pairlist_local))
+        return c ? (c->err = "bad argument", PGX_E_BADARG) : PGX_E_BADARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    (void)hipSetDevice(c->device);
+    if (!c->pairs_set) { c->err = "pgx_set_brief_pairs not called"; return PGX_E_NOT_CONFIGURED; }
+    const int words = c->words, r = c->comm_rank;
+    // phase 1: detect the frames this rank owns, straight into its block of the gathered buffers
+    uint32_t *desc_l = d_desc_all + (size_t)r * frame_slots * capacity * words;
+    int32_t *counts_l = d_counts_all + (size_t)r * frame_slots;
+    int rc = pgx_enqueue_detect(c, d_frames_local, n_local_frames, W, H, d_kp_local, desc_l, counts_l, d_nraw_local, capacity);
+    if (rc != PGX_OK) return rc;
+    // phase 2: the fixed-size per-frame records
+    if ((rc = allgather_locked(c, d_desc_all, (size_t)frame_slots * capacity * words * 4)) != PGX_OK) return rc;
+    if ((rc = allgather_locked(c, d_counts_all, (size_t)frame_slots * 4)) != PGX_OK) return rc;
+    // phase 3: the image pairs this rank owns (pair list pre-mapped to slots of the gathered buffer)
+    pgx_pair *out_l = d_out_all + (size_t)r * pair_slots * capacity;
+    rc = pgx_enqueue_match(c, d_desc_all, d_counts_all, capacity, words, d_pairlist_local, n_local_pairs, capacity, out_l);
+    if (rc != PGX_OK) return rc;
+    // phase 4: the fixed-size match lists
+    return allgather_locked(c, d_out_all, (size_t)pair_slots * capacity * sizeof(pgx_pair));
+}
+
+} // extern "C"

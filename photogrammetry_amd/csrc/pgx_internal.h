@@ -87,6 +87,10 @@ struct pgx_ctx {
     hipEvent_t ev_in = nullptr, ev_wide[3] = {nullptr, nullptr, nullptr}, ev_rows[3] = {nullptr, nullptr, nullptr},
                ev_fin[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
 
+    // multi-GPU: the RCCL communicator of this context's process (pgx_comm.hip); world 1 = none
+    void *comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+
     // profiling
     bool prof_on = false;
     std::map<std::string, ProfEntry> prof;

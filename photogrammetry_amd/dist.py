@@ -148,7 +148,12 @@ class ShardedSequence:
     `step()` only enqueues (pgx kernels and the collectives share `stream`).  Frames are addressed in
     the gathered buffers through slot_of(); the pair list handed to the matcher is pre-mapped."""
 
-    def __init__(self, engine, W, H, n_frames, pair_list, nkp, words, device, stream=None, group=None):
+    def __init__(self, engine, W, H, n_frames, pair_list, nkp, words, device, stream=None, group=None, comm="torch"):
+        """comm = "torch": the two exchanges are torch.distributed all_gather_into_tensor calls (RCCL under the "nccl"
+        backend, gloo in the CPU tests); comm = "pgx": the whole step is ONE C-ABI call, pgx_sequence_step_dev, on the
+        context's own RCCL communicator (engine.comm_init must have run; what a non-Python host would use)."""
+        assert comm in ("torch", "pgx")
+        self.comm = comm
         self.e, self.W, self.H, self.nkp, self.words = engine, W, H, nkp, words
         self.rank, self.world = _world()
         self.group = group
@@ -180,6 +185,10 @@ class ShardedSequence:
         """d_frames_local: uint16 [len(my_frames)][H][W][4] resident on this rank's GPU."""
         import contextlib
         nf, npr = len(self.my_frames), len(self.my_pairs)
+        if self.comm == "pgx":
+            self.e.sequence_step_dev(d_frames_local, nf, self.fs, self.W, self.H, self.kp_l, self.desc_all, self.counts_all,
+                                     self.nraw_l, self.nkp, self.pairlist_l, npr, self.ps, self.out_all)
+            return
         with (torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()):
             if nf:
                 self.e.detect_batch_dev(d_frames_local, nf, self.W, self.H, self.kp_l, self.desc_l, self.counts_l,

@@ -145,10 +145,10 @@ def test_match_batch_more_pairs_than_one_chunk(engine):
 
 def test_profile_hooks_and_stats(engine):
     rng = np.random.default_rng(9)
-    descs = [rng.integers(0, 2**32, (2000, 8), dtype=np.uint32) for _ in range(2)]
+    descs = [rng.integers(0, 2**32, (3000, 8), dtype=np.uint32) for _ in range(2)]   # > PGX_TAIL_MAX: a wide round runs
     engine.profile_reset()
     engine.profile_enable(True)
-    _match_batch(engine, descs, [2000, 2000], [(0, 1)], 2048)
+    _match_batch(engine, descs, [3000, 3000], [(0, 1)], 3072)
     engine.check_status()
     engine.profile_enable(False)
     n, ms = engine.profile_get("ham_argmin")
@@ -156,7 +156,8 @@ def test_profile_hooks_and_stats(engine):
     n2, ms2 = engine.profile_get("match_finish")
     assert n2 == 1 and ms2 > 0
     rounds, evals, ev0 = engine.match_stats()
-    assert rounds >= 1 and ev0 == 2000 * 2000 and evals >= ev0
+    assert rounds >= 1 and ev0 == 3000 * 3000 and evals >= ev0
+    assert engine.profile_get("tail_rows")[0] == 1
     engine.profile_reset()
     assert engine.profile_get("ham_argmin") == (0, 0.0)
 

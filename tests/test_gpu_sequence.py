@@ -225,3 +225,46 @@ def test_survivor_limit_cuts_silently_and_capacity_still_raises(engine):
     engine.set_capacity(1 << 17, 1 << 20)
     with pytest.raises(pg.CapacityError):
         engine.detect(frame, capacity=200)
+
+
+def test_c_abi_communicator_world1_and_sequence_step(engine):
+    """pgx_comm_* at world size 1 (RCCL really initialised on this GPU) and pgx_sequence_step_dev = the four phases in ONE
+    C call; its result must equal the torch-side ShardedSequence on the same frames.  (N > 1 runs on the 8-GPU node in
+    bench.py's c_abi_comm leg; the sharding arithmetic is covered by the world-2/3 gloo tests.)"""
+    W, H, NKP, radius, F = 640, 360, 1024, 12, 5
+    pairs = pg.make_brief_pairs(4, 40, 256)
+    engine.set_brief_pairs(pairs)
+    engine.set_detect_params(T, radius)
+    engine.set_capacity(1 << 17, NKP)
+    engine.set_dewarp_map(None)
+    frames = np.stack([synth.make_frame(W, H, seed=90 + i, n_shapes=900) for i in range(F)])
+    d_frames = torch.from_numpy(frames).to(DEV)
+    pl = pdist.all_pairs(F)
+    stream = torch.cuda.Stream(device=DEV)
+    assert engine.comm_info() == (0, 1)
+    uid = pg.comm_unique_id()
+    assert len(uid) == 128
+    engine.comm_init(0, 1, uid)
+    with pytest.raises(pg.ArgumentException):
+        engine.comm_init(0, 1, uid)                 # a context owns ONE communicator
+    assert engine.comm_info() == (0, 1)
+    ja = pdist.ShardedSequence(engine, W, H, F, pl, NKP, 8, DEV, stream=stream, comm="torch")
+    jb = pdist.ShardedSequence(engine, W, H, F, pl, NKP, 8, DEV, stream=stream, comm="pgx")
+    torch.cuda.synchronize()
+    ja.step(d_frames)
+    jb.step(d_frames)
+    jb.step(d_frames)
+    engine.allgather_dev(jb.out_all, jb.out_all.numel() * 4)      # world 1: a no-op on the context's stream
+    engine.check_status()
+    assert torch.equal(ja.counts_all, jb.counts_all) and int(ja.counts_all.min()) > 50
+    assert torch.equal(ja.desc_all, jb.desc_all) and torch.equal(ja.out_all, jb.out_all)
+    counts = jb.counts()
+    for m in (0, len(pl) - 1):
+        a, b = pl[m]
+        da = jb.descriptors(a).cpu().numpy().view(np.uint32)[:counts[a]]
+        db = jb.descriptors(b).cpu().numpy().view(np.uint32)[:counts[b]]
+        assert _same(jb.matches(m).cpu().numpy()[:counts[a]], cref.match_sorted(da, db))
+    engine.comm_destroy()
+    engine.comm_destroy()                           # idempotent
+    engine.set_stream(0)
+    engine.set_capacity(1 << 17, 1 << 20)
