@@ -138,6 +138,29 @@ int pgx_match_batch_dev(pgx_ctx *ctx, const uint32_t *d_desc, const int32_t *d_c
                         int stride, int words, const int32_t *d_pairlist, int M, int max_count,
                         pgx_pair *d_out);
 
+/* ---- RANSAC fundamental matrix and camera pose, batched over image pairs (asynchronous, device pointers) --- */
+/* CameraPoseEstimation.GetFundamentalMatrix (CameraPoseEstimation.cs:26-94) for M image pairs at once: `keypointPairs` of
+ * image pair m = the first counts[a] entries of d_matches[m] (indices into d_kp[a] / d_kp[b], (a, b) = d_pairlist[m]); per
+ * sample a subset of pairs_per_sample DISTINCT list positions, the normalised 8-point estimate (EstimateFundamentalMatrix,
+ * :204-250, incl. its always-1 scale and column-major fill), the signed score (F * p2) . p1 <= threshold over the whole list
+ * (:67-77); the first sample with the most inliers wins.  rank_check != 0 keeps only matrices of numerical rank 2 like
+ * :46-51 (with noisy pairs that rejects nearly every sample -- the reference then throws; here d_inliers[m] = -1).
+ * The reference draws subsets from an unseeded System.Random and singular vectors from MathNet's SVD: `seed` replaces the
+ * former, a Jacobi eigen-solver with a fixed sign rule the latter (parity unpinned).  d_F [M][9] row-major;
+ * d_inliers[m] = -1 when the list is shorter than pairs_per_sample (:31-32) or no sample qualified (:88-89).
+ * pairs_per_sample < 8 -> PGX_E_BADARG (:28-29). */
+int pgx_fundamental_ransac_dev(pgx_ctx *ctx, const pgx_keypoint *d_kp /* [F][stride] */, const pgx_pair *d_matches /* [M][stride] */,
+                               const int32_t *d_counts /* [F] */, const int32_t *d_pairlist /* [M][2] */, int M, int stride,
+                               int n_samples, int pairs_per_sample, float threshold, int rank_check, uint64_t seed,
+                               float *d_F, int32_t *d_inliers, int32_t *d_best_sample);
+/* CameraPoseEstimation.EstimateCameraPose (:96-202): E = K^T F K with the reference's hard-coded K, the four (R, t)
+ * candidates, linear triangulation of every keypoint pair, vote on z >= 0.  d_Rt [M][12] = R row-major then t of the
+ * winning candidate, d_votes [M][4], d_best [M]; d_points [M][stride][3] (or NULL) = the winner's point cloud (the input of
+ * Utils.CreatePointCloud, :199). */
+int pgx_pose_dev(pgx_ctx *ctx, const pgx_keypoint *d_kp, const pgx_pair *d_matches, const int32_t *d_counts,
+                 const int32_t *d_pairlist, int M, int stride, const float *d_F, float *d_Rt, int32_t *d_votes,
+                 int32_t *d_best, float *d_points);
+
 /* ---- multi-GPU: one process and one context per GPU; the context owns the RCCL communicator -------- */
 /* The reference handles one image pair in one process (TestService.cs:80-96) and nothing couples image pairs, so the
  * path shards with no collective inside detect or match: frame f -> rank f mod G, image pair p -> rank p mod G, and two
@@ -163,6 +186,19 @@ int pgx_sequence_step_dev(pgx_ctx *ctx, const uint16_t *d_frames_local, int n_lo
                           pgx_keypoint *d_kp_local, uint32_t *d_desc_all, int32_t *d_counts_all, int32_t *d_nraw_local,
                           int capacity, const int32_t *d_pairlist_local, int n_local_pairs, int pair_slots,
                           pgx_pair *d_out_all);
+
+/* ---- the track graph over the gathered match lists (host side, no GPU work) ------------------------- */
+/* Not in the reference.  Union-find over (frame, keypoint) nodes: a match of image pair (a, b) links
+ * (a, k1) with (b, k2) when dist <= max_dist; a union that would put two keypoints of ONE frame into a track is refused
+ * (first come, in list order).  counts [n_frames] = keypoints per frame. */
+typedef struct pgx_tracks pgx_tracks;
+int  pgx_tracks_create(const int32_t *counts, int n_frames, pgx_tracks **out);
+void pgx_tracks_destroy(pgx_tracks *t);
+/* matches: the first n entries of one image pair's list (n = counts[frame_a]); PGX_DIST_NONE tail entries never link. */
+int  pgx_tracks_add_pair(pgx_tracks *t, int frame_a, int frame_b, const pgx_pair *matches, int n, int max_dist);
+/* Tracks with at least min_len nodes, ordered by their first (frame, keypoint); nodes inside a track ascending. */
+int  pgx_tracks_finish(pgx_tracks *t, int min_len, int *n_tracks, int *n_nodes);
+int  pgx_tracks_get(pgx_tracks *t, int32_t *track_offsets /* [n_tracks + 1] */, int32_t *nodes /* [n_nodes][2] = (frame, keypoint) */);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------- */
 /* When on, the named hot kernels are bracketed by HIP events on the launch stream. */

@@ -17,21 +17,42 @@ using Microsoft.Extensions.Options;
 
 namespace ImageProcessing.Native;
 
-/// <summary>Replaces DeWarp.ApplyDistortionMat (DeWarp.cs:19-37); GetDistortionMatrix stays managed.</summary>
-public sealed unsafe class GpuDeWarp
+/// <summary>Replaces DeWarp.ApplyDistortionMat (DeWarp.cs:19-37).  The distortion table is handed to the library ONCE,
+/// in Initialize() -- the place where DeWarpTransformStepFactory forces its Lazy&lt;Matrix&lt;Uv&gt;&gt;
+/// (DeWarpTransformStepFactory.cs:23,26-31) -- never per image.</summary>
+public sealed unsafe class GpuDeWarp : IInitializable
 {
     private readonly PgxContext _ctx;
-    public GpuDeWarp(PgxContext ctx) => _ctx = ctx;
+    private readonly DeWarp _managed;               // GetDistortionMatrix stays managed (init-time, DeWarp.cs:39-107)
+    private readonly DeWarpOptions _options;
+    private bool _initialized;
+
+    public GpuDeWarp(PgxContext ctx, DeWarp managed, IOptions<DeWarpOptions> options)
+    {
+        _ctx = ctx; _managed = managed; _options = options.Value;
+    }
+
+    /// <summary>IInitializable.Initialize (PipelinesV3/IInitializable.cs:3-6): build the table, upload it once.</summary>
+    public void Initialize()
+    {
+        if (_initialized) return;
+        var map = _managed.GetDistortionMatrix();
+        int w = map.Dimensions.Width, h = map.Dimensions.Height;
+        var uv = new int[w * h * 2];                           // row-major (U, V)
+        for (ushort y = 0; y < h; y++)
+            for (ushort x = 0; x < w; x++)
+            { var m = map[x, y]; uv[(y * w + x) * 2] = m.U; uv[(y * w + x) * 2 + 1] = m.V; }
+        fixed (int* p = uv)
+            PgxNative.Check(_ctx.Handle, PgxNative.pgx_set_dewarp_map(_ctx.Handle, p, w, h));
+        // alternative without the managed cubic solver and the upload: the same table built on the device,
+        //   fixed (double* k = _options.DistortionCoefficients) PgxNative.pgx_set_dewarp_coeffs(_ctx.Handle, w, h, k, 5);
+        _initialized = true;
+    }
 
     /// <param name="rgba64">ImageSharp's contiguous Image&lt;Rgba64&gt; pixel memory, row-major [H][W][4].</param>
-    public void ApplyDistortionMat(ReadOnlySpan<ushort> rgba64, int width, int height, Matrix<Uv> map, Span<ushort> output)
+    public void ApplyDistortionMat(ReadOnlySpan<ushort> rgba64, int width, int height, Span<ushort> output)
     {
-        var uv = new int[width * height * 2];                  // row-major (U, V), built once in Initialize()
-        for (ushort y = 0; y < map.Dimensions.Height; y++)
-            for (ushort x = 0; x < map.Dimensions.Width; x++)
-            { var m = map[x, y]; uv[(y * map.Dimensions.Width + x) * 2] = m.U; uv[(y * map.Dimensions.Width + x) * 2 + 1] = m.V; }
-        fixed (int* p = uv)
-            PgxNative.Check(_ctx.Handle, PgxNative.pgx_set_dewarp_map(_ctx.Handle, p, map.Dimensions.Width, map.Dimensions.Height));
+        if (!_initialized) Initialize();
         fixed (ushort* src = rgba64) fixed (ushort* dst = output)
             PgxNative.Check(_ctx.Handle, PgxNative.pgx_dewarp(_ctx.Handle, src, width, height, dst)); // ArgumentException / IndexOutOfRangeException
     }

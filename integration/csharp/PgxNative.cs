@@ -37,6 +37,30 @@ internal static unsafe class PgxNative
     [DllImport(Lib)] public static extern int pgx_detect(IntPtr ctx, ushort* rgba64, int w, int h, PgxKeypoint* kp, uint* desc,
                                                          int capacity, out int n, out int nRaw);
 
+    // batched, device-resident entry points and the multi-GPU / pose / track-graph additions (include/pgx.h)
+    [DllImport(Lib)] public static extern int pgx_detect_batch_dev(IntPtr ctx, void* dRgba64, int f, int w, int h, void* dKp, void* dDesc,
+                                                                   void* dCounts, void* dNraw, int capacity);
+    [DllImport(Lib)] public static extern int pgx_match_batch_dev(IntPtr ctx, void* dDesc, void* dCounts, int stride, int words,
+                                                                  void* dPairlist, int m, int maxCount, void* dOut);
+    [DllImport(Lib)] public static extern int pgx_check_status(IntPtr ctx);
+    [DllImport(Lib)] public static extern int pgx_comm_unique_id(byte* id128);
+    [DllImport(Lib)] public static extern int pgx_comm_init(IntPtr ctx, int rank, int world, byte* id128);
+    [DllImport(Lib)] public static extern int pgx_comm_destroy(IntPtr ctx);
+    [DllImport(Lib)] public static extern int pgx_allgather_dev(IntPtr ctx, void* dBuf, nuint bytesPerRank);
+    [DllImport(Lib)] public static extern int pgx_sequence_step_dev(IntPtr ctx, void* dFramesLocal, int nLocalFrames, int frameSlots, int w, int h,
+                                                                    void* dKpLocal, void* dDescAll, void* dCountsAll, void* dNrawLocal, int capacity,
+                                                                    void* dPairlistLocal, int nLocalPairs, int pairSlots, void* dOutAll);
+    [DllImport(Lib)] public static extern int pgx_fundamental_ransac_dev(IntPtr ctx, void* dKp, void* dMatches, void* dCounts, void* dPairlist, int m,
+                                                                         int stride, int nSamples, int pairsPerSample, float threshold, int rankCheck,
+                                                                         ulong seed, float* dF, int* dInliers, int* dBestSample);
+    [DllImport(Lib)] public static extern int pgx_pose_dev(IntPtr ctx, void* dKp, void* dMatches, void* dCounts, void* dPairlist, int m, int stride,
+                                                           float* dF, float* dRt, int* dVotes, int* dBest, float* dPoints);
+    [DllImport(Lib)] public static extern int pgx_tracks_create(int* counts, int nFrames, out IntPtr tracks);
+    [DllImport(Lib)] public static extern void pgx_tracks_destroy(IntPtr tracks);
+    [DllImport(Lib)] public static extern int pgx_tracks_add_pair(IntPtr tracks, int frameA, int frameB, PgxPair* matches, int n, int maxDist);
+    [DllImport(Lib)] public static extern int pgx_tracks_finish(IntPtr tracks, int minLen, out int nTracks, out int nNodes);
+    [DllImport(Lib)] public static extern int pgx_tracks_get(IntPtr tracks, int* trackOffsets, int* nodes);
+
     /// <summary>Maps a status code back to the exception type the managed implementation throws.</summary>
     public static void Check(IntPtr ctx, int rc)
     {

@@ -193,6 +193,19 @@ class Engine:
                                               _dptr(d_pairlist), int(M),
                                               int(stride if max_count is None else max_count), _dptr(d_out)))
 
+    # -- RANSAC fundamental matrix / pose (device tensors) ------------------------------------------
+    def fundamental_ransac_dev(self, d_kp, d_matches, d_counts, d_pairlist, M, stride, n_samples, pairs_per_sample, threshold,
+                               d_F, d_inliers, d_best_sample, rank_check=False, seed=0):
+        self._chk(self._L.pgx_fundamental_ransac_dev(self._h, _dptr(d_kp), _dptr(d_matches), _dptr(d_counts), _dptr(d_pairlist),
+                                                     int(M), int(stride), int(n_samples), int(pairs_per_sample),
+                                                     C.c_float(threshold), 1 if rank_check else 0, C.c_uint64(seed),
+                                                     _dptr(d_F), _dptr(d_inliers), _dptr(d_best_sample)))
+
+    def pose_dev(self, d_kp, d_matches, d_counts, d_pairlist, M, stride, d_F, d_Rt, d_votes, d_best, d_points=None):
+        self._chk(self._L.pgx_pose_dev(self._h, _dptr(d_kp), _dptr(d_matches), _dptr(d_counts), _dptr(d_pairlist), int(M),
+                                       int(stride), _dptr(d_F), _dptr(d_Rt), _dptr(d_votes), _dptr(d_best),
+                                       _dptr(d_points) if d_points is not None else None))
+
     # -- multi-GPU: the context's own RCCL communicator (pgx_comm_*) ------------------------------
     def comm_init(self, rank, world, unique_id):
         """Collective: every rank calls this with the 128 bytes rank 0 got from comm_unique_id()."""

@@ -256,7 +256,7 @@ void pgx_ctx_destroy(pgx_ctx *c)
         for (auto &ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     DevBuf *bufs[] = {&c->d_pairs, &c->d_map, &c->ws_gray, &c->ws_seg, &c->ws_segoff, &c->ws_nraw, &c->ws_rawxy,
                       &c->ws_rawscore, &c->ws_nms, &c->ws_order, &c->ws_nkept, &c->st_a, &c->st_b, &c->st_c,
-                      &c->st_d, &c->st_e, &c->st_f, &c->ws_matchn[0], &c->ws_matchn[1], &c->ws_matchn[2]};
+                      &c->st_d, &c->st_e, &c->st_f, &c->ws_pose, &c->ws_matchn[0], &c->ws_matchn[1], &c->ws_matchn[2]};
     for (DevBuf *b : bufs) b->release();
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -564,6 +564,39 @@ int pgx_match_batch_dev(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_cou
         return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
     Lock l(c);
     return enqueue_match(c, d_desc, d_counts, stride, words, d_pairlist, M, max_count, d_out);
+}
+
+// ---- RANSAC fundamental matrix and pose ----------------------------------------------------------
+
+int pgx_fundamental_ransac_dev(pgx_ctx *c, const pgx_keypoint *d_kp, const pgx_pair *d_matches, const int32_t *d_counts,
+                               const int32_t *d_pairlist, int M, int stride, int n_samples, int pairs_per_sample,
+                               float threshold, int rank_check, uint64_t seed, float *d_F, int32_t *d_inliers,
+                               int32_t *d_best_sample)
+{
+    if (!c || !d_kp || !d_matches || !d_counts || !d_pairlist || !d_F || !d_inliers || !d_best_sample || M < 0 || stride <= 0)
+        return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    if (pairs_per_sample < 8) // CameraPoseEstimation.cs:28-29
+        return fail(c, PGX_E_BADARG, "At least 8 keypoint pairs must be included per sample (InvalidOperationException)");
+    if (pairs_per_sample > 64 || n_samples <= 0) return fail(c, PGX_E_BADARG, "pairs_per_sample must be <= 64 and n_samples > 0");
+    if (M == 0) return PGX_OK;
+    HIPCHK(c, c->ws_pose.ensure(pgx_pose_ws_bytes(M, n_samples)));
+    pgx_launch_fundamental(c->stream, d_kp, d_matches, d_counts, d_pairlist, M, stride, n_samples, pairs_per_sample, threshold,
+                           rank_check, seed, c->ws_pose.p, d_F, d_inliers, d_best_sample);
+    HIPCHK(c, hipGetLastError());
+    return PGX_OK;
+}
+
+int pgx_pose_dev(pgx_ctx *c, const pgx_keypoint *d_kp, const pgx_pair *d_matches, const int32_t *d_counts,
+                 const int32_t *d_pairlist, int M, int stride, const float *d_F, float *d_Rt, int32_t *d_votes,
+                 int32_t *d_best, float *d_points)
+{
+    if (!c || !d_kp || !d_matches || !d_counts || !d_pairlist || !d_F || !d_Rt || !d_votes || !d_best || M < 0 || stride <= 0)
+        return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    pgx_launch_pose(c->stream, d_kp, d_matches, d_counts, d_pairlist, M, stride, d_F, d_Rt, d_votes, d_best, d_points);
+    HIPCHK(c, hipGetLastError());
+    return PGX_OK;
 }
 
 // ---- measurement hooks ---------------------------------------------------------------------

@@ -83,6 +83,7 @@ struct pgx_ctx {
     DevBuf st_a, st_b, st_c, st_d, st_e, st_f;
     // match workspaces: three, so that with several chunks of image pairs the stages of consecutive chunks run side by side
     DevBuf ws_matchn[3];
+    DevBuf ws_pose;
     hipStream_t mstream[3] = {nullptr, nullptr, nullptr}; // [0] wide rounds, [1] residual distance rows, [2] per-pair finishes
     hipEvent_t ev_in = nullptr, ev_wide[3] = {nullptr, nullptr, nullptr}, ev_rows[3] = {nullptr, nullptr, nullptr},
                ev_fin[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -182,6 +183,15 @@ void pgx_launch_brief(hipStream_t s, const float *gray, int F, int W, int H,
 // descriptors for an explicit keypoint list (stage API)
 void pgx_launch_brief_list(hipStream_t s, const float *gray, int W, int H, const pgx_keypoint *kps, int n,
                            const int32_t *pairs, int P, uint32_t *desc_out);
+
+// k_pose.hip
+size_t pgx_pose_ws_bytes(int M, int n_samples);
+void pgx_launch_fundamental(hipStream_t s, const pgx_keypoint *kp, const pgx_pair *matches, const int32_t *counts,
+                            const int32_t *pairlist, int M, int stride, int n_samples, int P, float threshold, int rank_check,
+                            uint64_t seed, void *ws, float *F_out, int32_t *inliers, int32_t *best_sample);
+void pgx_launch_pose(hipStream_t s, const pgx_keypoint *kp, const pgx_pair *matches, const int32_t *counts,
+                     const int32_t *pairlist, int M, int stride, const float *F_in, float *Rt_out, int32_t *votes,
+                     int32_t *best, float *points);
 
 // k_match.hip
 struct MatchPlan {

@@ -125,6 +125,34 @@ def build_track_graph(counts_all, pair_list, matches_all, max_dist=64):
     return g
 
 
+def build_tracks_native(counts_all, pair_list, matches_all, max_dist=64, min_len=2):
+    """The same graph through the C ABI (pgx_tracks_*: what a non-Python host calls) -> list of tracks, each a list of
+    (frame, keypoint), in TrackGraph.tracks() order."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    m = matches_all.cpu().numpy() if isinstance(matches_all, torch.Tensor) else np.asarray(matches_all)
+    c = np.ascontiguousarray(counts_all.cpu().numpy() if isinstance(counts_all, torch.Tensor) else counts_all, dtype=np.int32)
+    h = C.c_void_p()
+    if L.pgx_tracks_create(C.c_void_p(c.ctypes.data), len(c), C.byref(h)) != 0:
+        raise RuntimeError("pgx_tracks_create failed")
+    try:
+        for p, (a, b) in enumerate(pair_list):
+            rows = np.ascontiguousarray(m[p][:int(c[a])], dtype=np.int32)
+            if L.pgx_tracks_add_pair(h, int(a), int(b), C.c_void_p(rows.ctypes.data), len(rows), int(max_dist)) != 0:
+                raise RuntimeError("pgx_tracks_add_pair failed")
+        nt, nn = C.c_int(0), C.c_int(0)
+        if L.pgx_tracks_finish(h, int(min_len), C.byref(nt), C.byref(nn)) != 0:
+            raise RuntimeError("pgx_tracks_finish failed")
+        off = np.zeros(nt.value + 1, dtype=np.int32)
+        nodes = np.zeros((max(nn.value, 1), 2), dtype=np.int32)
+        if L.pgx_tracks_get(h, C.c_void_p(off.ctypes.data), C.c_void_p(nodes.ctypes.data)) != 0:
+            raise RuntimeError("pgx_tracks_get failed")
+        return [[(int(f), int(k)) for f, k in nodes[off[t]:off[t + 1]]] for t in range(nt.value)]
+    finally:
+        L.pgx_tracks_destroy(h)
+
+
 # ---- the four phases on this rank's GPU ------------------------------------------------------------
 
 def slot_of(index, world, nslots):

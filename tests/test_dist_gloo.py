@@ -127,6 +127,24 @@ def test_sharding_helpers():
     assert (pdist.all_gather_slots(t, 3) == t[:3]).all()
 
 
+def test_native_track_graph_equals_python():
+    """pgx_tracks_* (C ABI) against dist.TrackGraph on the 5-frame sequence and on random lists with conflicts."""
+    desc, counts, pl, matches = _single_process()
+    for md in (25, 40, 300):
+        assert pdist.build_tracks_native(counts, pl, matches, max_dist=md) == \
+               [list(t) for t in pdist.build_track_graph(counts, pl, matches, max_dist=md).tracks()]
+    rng = np.random.default_rng(5)
+    counts = rng.integers(0, 9, 7).astype(np.int32)
+    pl = [(a, b) for a in range(7) for b in range(7) if a != b]
+    m = np.zeros((len(pl), 8, 3), dtype=np.int32)
+    m[..., 0] = rng.integers(0, 9, m.shape[:2])
+    m[..., 1] = rng.integers(0, 9, m.shape[:2])
+    m[..., 2] = rng.integers(0, 60, m.shape[:2])
+    for min_len in (1, 2, 3):
+        got = pdist.build_tracks_native(counts, pl, m, max_dist=30, min_len=min_len)
+        assert got == [list(t) for t in pdist.build_track_graph(counts, pl, m, max_dist=30).tracks(min_len=min_len)]
+
+
 def test_track_graph_rejects_same_frame_merges():
     g = pdist.TrackGraph([2, 2, 2])
     g.add_pair(0, 1, [[0, 0, 5], [1, 1, 99]], max_dist=10)       # second edge fails the distance gate
