@@ -678,6 +678,10 @@ void pgx_launch_match_rows(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, 
     if (plan.M <= 0 || plan.words != 8) return;
     uint32_t *ws = reinterpret_cast<uint32_t *>(wsv);
     ProfScope ps(ctx, "tail_rows", s);
+    if (pgx_mfma_enabled()) { // the matrix-pipe version (k_match_mfma.inc); PGX_DISABLE_MFMA=1 selects the xor+popcount one
+        hipLaunchKernelGGL(k_tail_rows_mfma, dim3(PGX_TAIL_MAX / TM_ROWS, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
+        return;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
