@@ -337,6 +337,7 @@ def worker(args):
 
     eng.profile_reset()
     eng.profile_enable(not args.no_profile)
+    eng.debug_counters()   # clears them
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -345,6 +346,8 @@ def worker(args):
     dt = time.perf_counter() - t0
     eng.profile_enable(False)
     eng.check_status()
+    dbg = eng.debug_counters()
+    tail_rounds_per_pair = dbg[3] / float(max(1, args.steps * max(1, len(job.my_pairs))))
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -473,6 +476,7 @@ def worker(args):
                            "wall_ms_per_step": max(step_ms - detect_ms, 0.0) if detect_ms else None,
                            "pairs_per_s": my_pairs_per_step / (max(step_ms - detect_ms, 1e-9) * 1e-3) if detect_ms else None,
                            "wide_rounds": rounds_wide, "evaluations_per_step": evals,
+                           "tail_rounds_per_image_pair": tail_rounds_per_pair,
                            "mfma_frac_of_peak_on_match_stage": (evals * 2.0 * P / (max(step_ms - detect_ms, 1e-9) * 1e-3)) / I8_MFMA_PEAK_OPS
                            if detect_ms else None,
                            "note": "match stage wall = step minus the detect kernels (rank 0); SURVEY 8d's match-only definition"},

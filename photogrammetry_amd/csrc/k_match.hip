@@ -300,6 +300,21 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     return v;
 }
 
+// the same for a wavefront whose 64 lanes are ALL active: six DPP row operations and one v_readlane instead of six
+// LDS-crossbar shuffles (each a ~60-cycle round trip); the result is wave-uniform
+__device__ __forceinline__ uint32_t wave_min_u32_full(uint32_t v)
+{
+    auto mn = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+    const int id = -1;
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x141, 0xF, 0xF, false)); // row_half_mirror
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x140, 0xF, 0xF, false)); // row_mirror
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x142, 0xA, 0xF, false)); // row_bcast:15 into rows 1, 3
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x143, 0xC, 0xF, false)); // row_bcast:31 into rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __host__ __device__ inline size_t tail_lds_words(int W)
 {
     // rl, cl, rbest, cbest, rdl, cdl (6 x TAIL_MAX) + alive flags (2 x TAIL_MAX bytes) + 8 counters + descriptors
