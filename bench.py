@@ -348,6 +348,7 @@ def worker(args):
     eng.check_status()
     dbg = eng.debug_counters()
     tail_rounds_per_pair = dbg[3] / float(max(1, args.steps * max(1, len(job.my_pairs))))
+    log('tail debug (rounds, row re-reads, re-read passes, proposals) per image pair:', [x / float(max(1, args.steps * max(1, len(job.my_pairs)))) for x in dbg[3:7]])
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
