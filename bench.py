@@ -348,6 +348,22 @@ def worker(args):
     eng.check_status()
     dbg = eng.debug_counters()
     tail_rounds_per_pair = dbg[3] / float(max(1, args.steps * max(1, len(job.my_pairs))))
+    kern_timed = kernel_table(eng, args.steps) if rank == 0 else {}
+    # stand-alone kernel times: in the timed region three matcher stages of consecutive chunks share the chip, so their
+    # event brackets overlap and stretch each other; a second, untimed pass runs the same steps with the stages in order
+    kern_alone, k_alone = {}, max(3, min(20, args.steps))
+    if not args.no_profile:
+        eng.profile_reset()
+        eng.profile_serialize(True)
+        eng.profile_enable(True)
+        for _ in range(k_alone):
+            job.step(d_frames)
+        torch.cuda.synchronize()
+        eng.profile_enable(False)
+        eng.profile_serialize(False)
+        eng.check_status()
+        if rank == 0:
+            kern_alone = kernel_table(eng, k_alone)
     log('tail debug (rounds, row re-reads, re-read passes, proposals) per image pair:', [x / float(max(1, args.steps * max(1, len(job.my_pairs)))) for x in dbg[3:7]])
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -388,7 +404,7 @@ def worker(args):
     rc = 0
     if rank == 0:
         F_l, M_l = len(job.my_frames), len(job.my_pairs)
-        kern = kernel_table(eng, args.steps)
+        kern = kern_timed
         rounds_wide, evals, evals0 = eng.match_stats()
         step_ms = dt_max / args.steps * 1e3
         match_ms = sum(kern[k]["ms_per_step"] for k in ("match_init", "ham_argmin", "match_select", "tail_fill", "tail_rows", "match_finish") if k in kern)
@@ -440,6 +456,13 @@ def worker(args):
                     "algorithmic": "2*P = 512 int8 ops per descriptor-pair evaluation x %d evaluations per step "
                                    "(device-counted: sum over launches and image pairs of n1*n2; %d wide rounds per chunk of 128 pairs)"
                                    % (evals, rounds_wide)}
+            if "ham_argmin" in kern_alone:
+                ta = kern_alone["ham_argmin"]["ms_per_step"] * 1e-3
+                mfma["standalone"] = {"achieved": ops / ta / 1e12, "frac": ops / ta / I8_MFMA_PEAK_OPS,
+                                      "ms_per_step": ta * 1e3,
+                                      "note": "the same steps with the matcher stages in order on one stream (pgx_profile_serialize): the kernel "
+                                              "alone on the chip; in the timed region it shares the chip with the residual-rows and per-pair "
+                                              "finish kernels of the neighbouring chunks, which stretches its event time"}
             rooflines["ham_argmin"] = mfma
         if detect_ms:
             byts = 24.0 * npix * F_l
@@ -470,8 +493,10 @@ def worker(args):
             "traffic_note": traffic_src,
             "rooflines": rooflines,
             "kernels": kern,
-            "kernels_note": "rank 0's HIP events around every launch of the timed steps; with several chunks of 128 image pairs "
-                            "match_finish runs on a second stream beside the next chunk's wide rounds, so the groups' sum can exceed ms_per_step",
+            "kernels_standalone": kern_alone,
+            "kernels_note": "kernels: rank 0's HIP events around every launch of the TIMED steps -- the matcher stages of consecutive chunks of "
+                            "128 image pairs run side by side on four streams, so their brackets overlap and the sum exceeds ms_per_step; "
+                            "kernels_standalone: the same steps again, untimed, stages in order on one stream",
             "detect": {"ms_per_step": detect_ms, "frames_per_s": F_l / (detect_ms * 1e-3) if detect_ms else None},
             "match_only": {"ms_per_step_sum_of_kernels": match_ms,
                            "wall_ms_per_step": max(step_ms - detect_ms, 0.0) if detect_ms else None,

@@ -207,6 +207,10 @@ int pgx_profile_enable(pgx_ctx *ctx, int on);
  * launches and total milliseconds.  Synchronises the stream. */
 int pgx_profile_get(pgx_ctx *ctx, const char *name, int *launches, double *total_ms);
 int pgx_profile_reset(pgx_ctx *ctx);
+/* When on, a multi-chunk pgx_match_batch_dev runs its stages in order on the context's stream instead of side by side on
+ * the library's own streams: the event times above are then stand-alone kernel times (side by side they overlap and
+ * stretch each other). */
+int pgx_profile_serialize(pgx_ctx *ctx, int on);
 /* Counters of the last pgx_match* call: rounds run on the all-CU distance kernel, and the
  * descriptor-pair distance evaluations those launches issued (sum over rounds and image pairs of
  * n1*n2; evaluations_round0 = the first launch alone = sum of N1*N2).  Synchronises the stream. */

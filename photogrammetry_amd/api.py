@@ -246,6 +246,9 @@ class Engine:
     def profile_enable(self, on=True):
         self._chk(self._L.pgx_profile_enable(self._h, 1 if on else 0))
 
+    def profile_serialize(self, on=True):
+        self._chk(self._L.pgx_profile_serialize(self._h, 1 if on else 0))
+
     def profile_reset(self):
         self._chk(self._L.pgx_profile_reset(self._h))
 

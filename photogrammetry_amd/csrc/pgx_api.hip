@@ -141,7 +141,7 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     if (plan.rounds_mfma > 0 && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS) plan.rounds_mfma++;
     HIPCHK(c, hipMemsetAsync(c->d_status + 4, 0, PGX_MAX_WIDE_ROUNDS * 8, c->stream));
     static const bool overlap = [] { const char *e = getenv("PGX_MATCH_OVERLAP"); return !(e && e[0] == '0'); }(); // developer A/B switch
-    if (M <= CHUNK || !overlap) { // everything in order on the context's stream
+    if (M <= CHUNK || !overlap || c->prof_serial) { // everything in order on the context's stream
         for (int m0 = 0; m0 < M; m0 += CHUNK) {
             plan.M = (M - m0 < CHUNK) ? M - m0 : CHUNK;
             const int32_t *pl = d_pairlist + 2 * (size_t)m0;
@@ -151,11 +151,13 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
         }
     } else {
         // Several chunks: a three-stage pipeline over chunks on three streams -- the whole-chip mutual-nearest rounds
-        // (matrix pipe) of chunk i + 2 beside the residual distance rows (vector ALU) of chunk i + 1 beside the per-pair
-        // finish (latency-bound, one small workgroup per pair) of chunk i.  Three workspaces rotate; events order
-        // "inputs ready -> wide(i) -> rows(i) -> finish(i) -> wide(i + 3)".  Each stream sits in a stream-priority class
-        // of its own where the device has three: streams of one class share a small pool of hardware queues round-robin,
-        // and two streams on one queue run strictly in order.
+        // (matrix pipe) of chunk i + 2 beside the residual distance rows (matrix pipe + stores) of chunk i + 1 beside the
+        // per-pair finish of chunk i (latency-bound, one small workgroup per pair on half of the CUs).  Three workspaces
+        // rotate; events order "inputs ready -> wide(i) -> rows(i) -> finish(i) -> wide(i + 3)".  The streams sit in
+        // different stream-priority classes where the device has three: streams of one class share a small pool of hardware
+        // queues round-robin, and two streams that land on one queue run strictly in order.  (Two finishes in flight on
+        // alternating streams were measured too: 15.3 ms per step of config 3 against 12.6 -- their registers and LDS
+        // crowd the matrix kernels out of every CU.)
         const int NS = 3;
         int lo = 0, hi = 0;
         HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi)); // lo = least priority (numerically greatest)
@@ -171,12 +173,13 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
             if (!c->ev_join[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
         }
         if (!c->ev_in) HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-        hipStream_t sw = c->mstream[0], sr = c->mstream[1], sf = c->mstream[2];
+        hipStream_t sw = c->mstream[0], sr = c->mstream[1];
         HIPCHK(c, hipEventRecord(c->ev_in, c->stream));
         for (int k = 0; k < NS; k++) HIPCHK(c, hipStreamWaitEvent(c->mstream[k], c->ev_in, 0));
         int i = 0;
         for (int m0 = 0; m0 < M; m0 += CHUNK, i++) {
             const int b = i % NS;
+            hipStream_t sf = c->mstream[2];
             void *ws = c->ws_matchn[b].p;
             const int32_t *pl = d_pairlist + 2 * (size_t)m0;
             plan.M = (M - m0 < CHUNK) ? M - m0 : CHUNK;
@@ -254,13 +257,14 @@ void pgx_ctx_destroy(pgx_ctx *c)
     if (c->comm) (void)pgx_comm_destroy(c);
     for (auto &kv : c->prof)
         for (auto &ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
     DevBuf *bufs[] = {&c->d_pairs, &c->d_map, &c->ws_gray, &c->ws_seg, &c->ws_segoff, &c->ws_nraw, &c->ws_rawxy,
                       &c->ws_rawscore, &c->ws_nms, &c->ws_order, &c->ws_nkept, &c->st_a, &c->st_b, &c->st_c,
-                      &c->st_d, &c->st_e, &c->st_f, &c->ws_pose, &c->ws_matchn[0], &c->ws_matchn[1], &c->ws_matchn[2]};
+                      &c->st_d, &c->st_e, &c->st_f, &c->ws_pose, &c->ws_matchn[0], &c->ws_matchn[1], &c->ws_matchn[2], &c->ws_matchn[3]};
     for (DevBuf *b : bufs) b->release();
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 4; k++) {
         if (c->mstream[k]) (void)hipStreamDestroy(c->mstream[k]);
         if (c->ev_wide[k]) (void)hipEventDestroy(c->ev_wide[k]);
         if (c->ev_rows[k]) (void)hipEventDestroy(c->ev_rows[k]);
@@ -618,8 +622,8 @@ static void prof_drain(pgx_ctx *c)
                 kv.second.total_ms += ms;
                 kv.second.launches += 1;
             }
-            (void)hipEventDestroy(ev.first);
-            (void)hipEventDestroy(ev.second);
+            c->ev_pool.push_back(ev.first);
+            c->ev_pool.push_back(ev.second);
         }
         kv.second.pending.clear();
     }
@@ -634,6 +638,14 @@ int pgx_profile_get(pgx_ctx *c, const char *name, int *launches, double *total_m
     auto it = c->prof.find(name);
     if (launches) *launches = it == c->prof.end() ? 0 : it->second.launches;
     if (total_ms) *total_ms = it == c->prof.end() ? 0.0 : it->second.total_ms;
+    return PGX_OK;
+}
+
+int pgx_profile_serialize(pgx_ctx *c, int on)
+{
+    if (!c) return PGX_E_BADARG;
+    Lock l(c);
+    c->prof_serial = on != 0;
     return PGX_OK;
 }
 

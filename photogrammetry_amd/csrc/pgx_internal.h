@@ -81,12 +81,12 @@ struct pgx_ctx {
     DevBuf ws_gray, ws_seg, ws_segoff, ws_nraw, ws_rawxy, ws_rawscore, ws_nms, ws_order, ws_nkept;
     // host-API staging
     DevBuf st_a, st_b, st_c, st_d, st_e, st_f;
-    // match workspaces: three, so that with several chunks of image pairs the stages of consecutive chunks run side by side
-    DevBuf ws_matchn[3];
+    // match workspaces: four, so that with several chunks of image pairs the stages of consecutive chunks run side by side
+    DevBuf ws_matchn[4];
     DevBuf ws_pose;
-    hipStream_t mstream[3] = {nullptr, nullptr, nullptr}; // [0] wide rounds, [1] residual distance rows, [2] per-pair finishes
-    hipEvent_t ev_in = nullptr, ev_wide[3] = {nullptr, nullptr, nullptr}, ev_rows[3] = {nullptr, nullptr, nullptr},
-               ev_fin[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipStream_t mstream[4] = {nullptr, nullptr, nullptr, nullptr}; // [0] wide rounds, [1] residual distance rows, [2], [3] per-pair finishes (alternating)
+    hipEvent_t ev_in = nullptr, ev_wide[4] = {nullptr, nullptr, nullptr, nullptr}, ev_rows[4] = {nullptr, nullptr, nullptr, nullptr},
+               ev_fin[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
 
     // multi-GPU: the RCCL communicator of this context's process (pgx_comm.hip); world 1 = none
     void *comm = nullptr;
@@ -94,7 +94,9 @@ struct pgx_ctx {
 
     // profiling
     bool prof_on = false;
+    bool prof_serial = false; // matcher stages in order on one stream (stand-alone kernel times)
     std::map<std::string, ProfEntry> prof;
+    std::vector<hipEvent_t> ev_pool; // recycled timing events (creating two per launch costs more than the record itself)
 
     // last match stats
     int last_rounds_mfma = 0;
@@ -131,7 +133,11 @@ struct ProfScope {
     {
         if (!c->prof_on) return;
         e = &c->prof[name];
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { e = nullptr; return; }
+        auto take = [&](hipEvent_t &ev) {
+            if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); return true; }
+            return hipEventCreate(&ev) == hipSuccess;
+        };
+        if (!take(a) || !take(b)) { e = nullptr; return; }
         (void)hipEventRecord(a, st);
     }
     ~ProfScope()
