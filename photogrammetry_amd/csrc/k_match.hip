@@ -17,12 +17,15 @@
 //
 // Kernels
 //   k_match_init      identity lists, keys, counters
-//   k_ham_valu        xor+popcount distance/argmin, one thread per row, columns broadcast
-//                     from LDS; both directions in one grid (generic in `words`)
-//   k_ham_mfma        (words == 8) int8 MFMA formulation, see below
+//   k_ham_mfma        (256-bit descriptors) int8 MFMA distance + fused row/column argmin, k_match_mfma.inc
+//   k_ham_valu        xor+popcount distance/argmin for any descriptor length (or PGX_DISABLE_MFMA=1)
 //   k_match_select    one workgroup per image pair: accept mutual edges, compact the lists
-//   k_match_finish    one workgroup per image pair: runs the remaining rounds in-kernel, then
-//                     sorts (bitonic, LDS) and writes the N1 output entries
+//   256-bit descriptors, once a pair's residual is <= PGX_TAIL_MAX (k_match_tail.inc, k_match_mfma.inc):
+//   k_tail_rows_mfma  residual distance rows (u8) + every row's nearest column, on the matrix pipe
+//   k_match_gs        one workgroup per image pair: row-proposing deferred acceptance, sort, the N1 output entries
+//   other descriptor lengths:
+//   k_match_finish    one workgroup per image pair: remaining rounds in-kernel (LDS tail below PGX_TAIL_FILL_MAX),
+//                     sort (bitonic, LDS), the N1 output entries
 #include "pgx_internal.h"
 
 namespace {
@@ -321,68 +324,6 @@ __host__ __device__ inline size_t tail_lds_words(int W)
     return (size_t)6 * TAIL_MAX + (size_t)2 * TAIL_MAX / 4 + 8 + (size_t)2 * PGX_TAIL_FILL_MAX * W;
 }
 
-// Wide fill of the tail's cached distance matrices: once an image pair's residual fits the tail
-// (<= TAIL_MAX rows and columns) every entry of D (and of its transpose) is computed exactly once by
-// the whole chip instead of by the pair's single tail workgroup.  One wavefront per matrix row, two
-// adjacent entries per lane (dword stores); side 0 writes D[i][j] and the row bests, side 1 the
-// transpose and the column bests (keys carry LOCAL indices = positions in the compacted lists and
-// go to rowkey/colkey, which the wide rounds no longer need for this pair).
-__global__ __launch_bounds__(256) void k_tail_fill(uint32_t *ws, const uint32_t *__restrict__ desc,
-                                                   const int32_t *__restrict__ pairlist, int S)
-{
-    const int side = blockIdx.y, m = blockIdx.z;
-    PairWs p = pair_ws(ws, m, S);
-    const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2], parity = p.cnt[CNT_PARITY];
-    if (n1 <= 0 || n2 <= 0 || n1 > TAIL_MAX || n2 > TAIL_MAX) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t *dX = desc + (size_t)pairlist[2 * m + side] * S * 8;
-    const uint32_t *dY = desc + (size_t)pairlist[2 * m + (side ^ 1)] * S * 8;
-    const uint32_t *xl = side ? (parity ? p.cols1 : p.cols0) : (parity ? p.rows1 : p.rows0);
-    const uint32_t *yl = side ? (parity ? p.rows1 : p.rows0) : (parity ? p.cols1 : p.cols0);
-    const int nx = side ? n2 : n1, ny = side ? n1 : n2;
-    const int ystride = (ny + 7) & ~7;
-    uint16_t *mat = p.dcache + (side ? (size_t)PGX_TAIL_MAX * PGX_TAIL_MAX : 0);
-    uint32_t *bestout = side ? p.colkey : p.rowkey;
-    // four matrix rows per wavefront: every gathered column descriptor is used four times
-    const int i0 = (blockIdx.x * 4 + wv) * 4;
-    if (blockIdx.x == 0 && side == 0 && threadIdx.x == 0) p.cnt[CNT_FILLED] = 1;
-    if (i0 >= nx) return; // wave-uniform
-    uint4 a0[4], a1[4];
-    uint32_t best[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int i = i0 + u < nx ? i0 + u : nx - 1; // duplicates of the last row are computed and dropped
-        a0[u] = *reinterpret_cast<const uint4 *>(dX + (size_t)xl[i] * 8);
-        a1[u] = *reinterpret_cast<const uint4 *>(dX + (size_t)xl[i] * 8 + 4);
-        best[u] = PGX_KEY_NONE;
-    }
-    for (int j2 = lane * 2; j2 < ystride; j2 += 128) {
-        const bool v0 = j2 < ny, v1 = j2 + 1 < ny;
-        const uint32_t *bp0 = dY + (size_t)yl[v0 ? j2 : 0] * 8, *bp1 = dY + (size_t)yl[v1 ? j2 + 1 : 0] * 8;
-        const uint4 b00 = *reinterpret_cast<const uint4 *>(bp0), b01 = *reinterpret_cast<const uint4 *>(bp0 + 4);
-        const uint4 b10 = *reinterpret_cast<const uint4 *>(bp1), b11 = *reinterpret_cast<const uint4 *>(bp1 + 4);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            uint32_t d0 = __popc(a0[u].x ^ b00.x) + __popc(a0[u].y ^ b00.y) + __popc(a0[u].z ^ b00.z) + __popc(a0[u].w ^ b00.w) +
-                          __popc(a1[u].x ^ b01.x) + __popc(a1[u].y ^ b01.y) + __popc(a1[u].z ^ b01.z) + __popc(a1[u].w ^ b01.w);
-            uint32_t d1 = __popc(a0[u].x ^ b10.x) + __popc(a0[u].y ^ b10.y) + __popc(a0[u].z ^ b10.z) + __popc(a0[u].w ^ b10.w) +
-                          __popc(a1[u].x ^ b11.x) + __popc(a1[u].y ^ b11.y) + __popc(a1[u].z ^ b11.z) + __popc(a1[u].w ^ b11.w);
-            const uint32_t k0 = v0 ? ((d0 << PGX_IDX_BITS) | (uint32_t)j2) : PGX_KEY_NONE;
-            const uint32_t k1 = v1 ? ((d1 << PGX_IDX_BITS) | (uint32_t)(j2 + 1)) : PGX_KEY_NONE;
-            best[u] = k0 < best[u] ? k0 : best[u];
-            best[u] = k1 < best[u] ? k1 : best[u];
-            d0 = v0 ? d0 : 0xFFFFu;
-            d1 = v1 ? d1 : 0xFFFFu;
-            if (i0 + u < nx) *reinterpret_cast<uint32_t *>(mat + (size_t)(i0 + u) * ystride + j2) = d0 | (d1 << 16);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const uint32_t b = wave_min_u32(best[u]);
-        if (lane == 0 && i0 + u < nx) bestout[i0 + u] = b;
-    }
-}
-
 template <int WORDS>
 __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict__ dA, const uint32_t *__restrict__ dB,
                                 int words_rt, uint32_t *lds, int *dbg)
@@ -398,7 +339,6 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
     uint8_t *ralive = reinterpret_cast<uint8_t *>(cdl + TAIL_MAX), *calive = ralive + TAIL_MAX;
     uint32_t *ctr = reinterpret_cast<uint32_t *>(calive + TAIL_MAX); // [0] dirty rows [1] dirty cols [2] accepted [3] alive rows [4] alive cols
     uint32_t *rdesc = ctr + 8, *cdesc = rdesc + (size_t)PGX_TAIL_FILL_MAX * W; // only used when this kernel fills D itself
-    const bool prefilled = p.cnt[CNT_FILLED] != 0;
     const uint32_t *rows = (parity ? p.rows1 : p.rows0), *cols = (parity ? p.cols1 : p.cols0);
 
     __syncthreads();
@@ -406,10 +346,9 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
     __syncthreads();
     for (int i = tid; i < R; i += nth) { rl[i] = rows[i]; rdl[i] = (uint32_t)i; ralive[i] = 1; rbest[i] = PGX_KEY_NONE; }
     for (int j = tid; j < C; j += nth) { cl[j] = cols[j]; cdl[j] = (uint32_t)j; calive[j] = 1; cbest[j] = PGX_KEY_NONE; }
-    if (!prefilled) { // word-major images (desc[w][k]) so that lanes reading neighbouring descriptors hit neighbouring banks
-        for (int t = tid; t < R * W; t += nth) rdesc[(size_t)(t % W) * PGX_TAIL_FILL_MAX + t / W] = dA[(size_t)rows[t / W] * W + (t % W)];
-        for (int t = tid; t < C * W; t += nth) cdesc[(size_t)(t % W) * PGX_TAIL_FILL_MAX + t / W] = dB[(size_t)cols[t / W] * W + (t % W)];
-    }
+    // word-major images (desc[w][k]) so that lanes reading neighbouring descriptors hit neighbouring banks
+    for (int t = tid; t < R * W; t += nth) rdesc[(size_t)(t % W) * PGX_TAIL_FILL_MAX + t / W] = dA[(size_t)rows[t / W] * W + (t % W)];
+    for (int t = tid; t < C * W; t += nth) cdesc[(size_t)(t % W) * PGX_TAIL_FILL_MAX + t / W] = dB[(size_t)cols[t / W] * W + (t % W)];
     if (tid == 0) { ctr[0] = (uint32_t)R; ctr[1] = (uint32_t)C; ctr[2] = 0; ctr[3] = 0; ctr[4] = 0; }
     __syncthreads();
 
@@ -451,13 +390,8 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
             if (lane == 0) bestout[i] = best;
         }
     };
-    if (prefilled) { // done by k_tail_fill on the whole chip; pick up the first bests
-        for (int i = tid; i < R; i += nth) rbest[i] = p.rowkey[i];
-        for (int j = tid; j < C; j += nth) cbest[j] = p.colkey[j];
-    } else {
-        fill(rdesc, R, cdesc, C, Cs, D, rbest);
-        fill(cdesc, C, rdesc, R, Rs, DT, cbest);
-    }
+    fill(rdesc, R, cdesc, C, Cs, D, rbest);
+    fill(cdesc, C, rdesc, R, Rs, DT, cbest);
     if (tid == 0) { ctr[0] = 0; ctr[1] = 0; }
     __syncthreads();
 
@@ -585,7 +519,7 @@ __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uin
     while (true) {
         const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2];
         if (n1 <= 0 || n2 <= 0) break; // uniform: cnt is only written behind barriers
-        const int lim = p.cnt[CNT_FILLED] ? TAIL_MAX : PGX_TAIL_FILL_MAX; // without the wide fill the descriptors must fit LDS
+        const int lim = PGX_TAIL_FILL_MAX; // the descriptors of the residual must fit LDS
         if (tail_in_lds && n1 <= lim && n2 <= lim) {
             tail_rounds_lds<WORDS>(p, parity, dA, dB, words, lds, status + 24);
             break;
@@ -718,6 +652,5 @@ void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc
         const size_t key_cap = n2p <= 8192 ? n2p : 0; // sort keys in LDS up to 32 KiB, else in the workspace
         hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(GS_NT), key_cap * 4, s, ws, d_desc, d_pairlist, plan.stride, d_out,
                            (uint32_t)key_cap, status);
-        launch_finish<8>(s, ws, d_desc, d_pairlist, plan, d_out, status); // only pairs k_match_gs declined (residual too large, or a distance of 256)
     } else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out, status);
 }

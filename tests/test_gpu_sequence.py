@@ -268,3 +268,24 @@ def test_c_abi_communicator_world1_and_sequence_step(engine):
     engine.comm_destroy()                           # idempotent
     engine.set_stream(0)
     engine.set_capacity(1 << 17, 1 << 20)
+
+
+def test_tail_fallback_distance_256_and_oversized_residual(engine):
+    """The two cases k_tail_rows leaves to the any-size form inside k_match_gs: (a) complementary descriptors (distance
+    256 does not fit the byte matrix), (b) a residual that is still larger than PGX_TAIL_MAX after the planned wide rounds
+    (all-identical descriptors: every round accepts exactly one edge).  Both against the oracle."""
+    rng = np.random.default_rng(256)
+    a = rng.integers(0, 2**32, (300, 8), dtype=np.uint32)
+    b = np.concatenate([~a[:40], rng.integers(0, 2**32, (200, 8), dtype=np.uint32), a[100:130]])[rng.permutation(270)]
+    a[5] = 0
+    b[7] = 0xFFFFFFFF                                          # an exact (0, all-ones) pair as well
+    ident1 = np.full((2200, 8), 0x5A5A5A5A, dtype=np.uint32)
+    ident2 = np.full((2150, 8), 0x5A5A5A5A, dtype=np.uint32)
+    ident2[::7, 3] ^= 1                                        # a few at distance 1
+    sets = [a, np.ascontiguousarray(b), ident1, ident2]
+    pl = [(0, 1), (1, 0), (2, 3)]
+    out = _match_dev(engine, sets, pl, 2304)
+    bits = lambda d: np.unpackbits(d.view(np.uint8), axis=1).astype(np.int32)
+    assert ((bits(a)[:, None, :] != bits(sets[1])[None, :, :]).sum(2) == 256).any()   # the byte matrix would overflow
+    for m, (x, y) in enumerate(pl):
+        assert _same(out[m][:len(sets[x])], cref.match_sorted(sets[x], sets[y])), (x, y)
