@@ -96,25 +96,48 @@ def spawn_ranks(args, argv):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
+    import tempfile
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "PGX_BENCH_CHILD": "1"})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
-    sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    # wait for all ranks; one failed rank means the others may sit in a rendezvous for minutes: stop exactly the processes
+    # started here (by handle, never by pattern) and report failure
+    bad = []
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad or all(rc is not None for rc in rcs):
+            break
+        time.sleep(0.2)
+    if bad:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    out0.seek(0)
+    lines = out0.read().decode(errors="replace").splitlines()
+    js = [ln for ln in lines if ln.startswith("{")]
+    for ln in lines:   # anything else a library wrote to rank 0's stdout goes to stderr: stdout carries the ONE JSON line
+        if not ln.startswith("{"):
+            log(ln)
     if bad:
         log("bench.py: ranks failed (rank, exit code): %s" % bad)
         return 1
-    if not any(line.startswith("{") for line in out0.splitlines()):
+    if not js:
         log("bench.py: rank 0 printed no JSON line")
         return 1
+    print(js[-1], flush=True)
     return 0
 
 
@@ -287,7 +310,12 @@ def worker(args):
     if args.gpus != world:
         log("bench.py: --gpus %d but WORLD_SIZE is %d: refusing to report a run on a different number of GPUs" % (args.gpus, world))
         return 2
+    # PGX_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend -- a functional rehearsal of the N > 1 code path on a
+    # one-GPU box (sharding, slot addressing, in-place all-gathers between real pgx contexts); its timing means nothing
+    rehearse = os.environ.get("PGX_BENCH_REHEARSE") == "1"
     ndev = torch.cuda.device_count()
+    if rehearse:
+        local_rank = 0
     if local_rank >= ndev:
         log("bench.py: rank %d needs GPU %d but only %d visible: --gpus %d cannot run here" % (rank, local_rank, ndev, world))
         return 3
@@ -295,7 +323,10 @@ def worker(args):
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     t_setup = time.time()
     nseq = world if args.scaling == "weak" else 1
@@ -399,7 +430,7 @@ def worker(args):
     # N > 1: the same job once more through the C ABI's own communicator (pgx_comm_init / pgx_sequence_step_dev: what a
     # non-Python host would call) -- results must equal the torch.distributed run; informative, never `value`
     c_abi = None
-    if world > 1:
+    if world > 1 and not rehearse:
         try:
             box = [pg.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
@@ -512,7 +543,8 @@ def worker(args):
                        "raw_hits_mean": float(nraw_l.mean()) if len(nraw_l) else 0.0,
                        "parallelism": "frames f mod %d, image pairs p mod %d; 2 all-gathers per step%s"
                                       % (world, world, "" if world > 1 else " (elided at N = 1)"),
-                       "jobs_in_flight": NI},
+                       "jobs_in_flight": NI,
+                       "rehearsal_on_one_gpu_with_gloo": rehearse},
             "roofline": rooflines.get(dominant),
             "mfma": mfma,
             "c_abi_comm": c_abi,

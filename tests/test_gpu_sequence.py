@@ -289,3 +289,78 @@ def test_tail_fallback_distance_256_and_oversized_residual(engine):
     assert ((bits(a)[:, None, :] != bits(sets[1])[None, :, :]).sum(2) == 256).any()   # the byte matrix would overflow
     for m, (x, y) in enumerate(pl):
         assert _same(out[m][:len(sets[x])], cref.match_sorted(sets[x], sets[y])), (x, y)
+
+
+def _two_rank_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # RCCL refuses two ranks on one GPU; gloo moves CUDA tensors
+    try:
+        W, H, NKP, radius, F = 640, 360, 1024, 12, 7
+        e = pg.Engine(0)
+        e.set_brief_pairs(pg.make_brief_pairs(4, 40, 256))
+        e.set_detect_params(T, radius)
+        e.set_capacity(1 << 17, NKP)
+        e.set_dewarp_map(None)
+        frames = np.stack([synth.make_frame(W, H, seed=90 + i, n_shapes=900) for i in range(F)])
+        pl = pdist.all_pairs(F)
+        job = pdist.ShardedSequence(e, W, H, F, pl, NKP, 8, DEV, stream=torch.cuda.Stream(device=DEV))
+        mine = torch.from_numpy(np.stack([frames[f] for f in job.my_frames])).to(DEV)
+        torch.cuda.synchronize()
+        job.step(mine)
+        job.step(mine)
+        e.check_status()
+        torch.cuda.synchronize()
+        desc = np.stack([job.descriptors(f).cpu().numpy() for f in range(F)])
+        out = np.stack([job.matches(p).cpu().numpy() for p in range(len(pl))])
+        q.put((rank, desc, job.counts(), out))
+        e.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_and_three_ranks_sharing_this_gpu_equal_one_rank(engine):
+    """The N > 1 path on real pgx contexts: 2 and 3 processes (one context each, all on GPU 0, gloo carrying the CUDA
+    tensors) run ShardedSequence on 7 frames / 21 image pairs (uneven shares); every rank must end with exactly the
+    descriptors, counts and match lists of the one-process run."""
+    import socket
+    import torch.multiprocessing as mp
+    W, H, NKP, radius, F = 640, 360, 1024, 12, 7
+    engine.set_brief_pairs(pg.make_brief_pairs(4, 40, 256))
+    engine.set_detect_params(T, radius)
+    engine.set_capacity(1 << 17, NKP)
+    engine.set_dewarp_map(None)
+    frames = np.stack([synth.make_frame(W, H, seed=90 + i, n_shapes=900) for i in range(F)])
+    pl = pdist.all_pairs(F)
+    ref = pdist.ShardedSequence(engine, W, H, F, pl, NKP, 8, DEV, stream=torch.cuda.Stream(device=DEV))
+    d_frames = torch.from_numpy(frames).to(DEV)
+    torch.cuda.synchronize()
+    ref.step(d_frames)
+    engine.check_status()
+    torch.cuda.synchronize()
+    rdesc = np.stack([ref.descriptors(f).cpu().numpy() for f in range(F)])
+    rout = np.stack([ref.matches(p).cpu().numpy() for p in range(len(pl))])
+    rcounts = ref.counts()
+    assert rcounts.min() > 50
+    for world in (2, 3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results = [q.get(timeout=300) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        for rank, d, c, o in results:
+            assert (c == rcounts).all(), (world, rank)
+            assert (d == rdesc).all() and (o == rout).all(), (world, rank)
+    engine.set_stream(0)
+    engine.set_capacity(1 << 17, 1 << 20)
