@@ -42,8 +42,9 @@ struct NmsLayout {
     int R;     // neighbourhood reach in cells: every point within r of a cell's point lies in the (2R+1)^2 block
     int champ; // 1: "champion" rounds (cells small enough that any two points of a cell are within r)
     int cgw;   // width of the champion grid, padded by R empty cells on every side
+    int mask;  // 1: champion rounds on per-cell 64-bit pixel masks (8-pixel cells), no per-hit records at all
     size_t off_cellstart, off_cellfill, off_cellund, off_counters, off_rec, off_listA, off_listB, off_accflag, off_sortkeys,
-        off_champ, total;
+        off_champ, off_alive, off_planes, off_disk, total;
 };
 
 // champion rounds need: the FAST planes (cells aligned to the 64-pixel segments, scores 12..16, raster ranks),
@@ -54,7 +55,13 @@ __host__ __device__ inline int nms_champ_cs(int radius, int n_cap, bool planes)
     return radius >= 90 ? 64 : (radius >= 44 ? 32 : (radius >= 22 ? 16 : 8));
 }
 
-__host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_cap, bool planes)
+// mask rounds: 8-pixel cells (r = 10..21) on frames whose coordinates fit 14 bits each (position-ordered 32-bit keys)
+__host__ __device__ inline bool nms_mask_ok(int W, int H, int radius, int n_cap, bool planes, bool allow)
+{
+    return allow && nms_champ_cs(radius, n_cap, planes) == 8 && W <= 16384 && H <= 16384;
+}
+
+__host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_cap, bool planes, bool allow_mask = true)
 {
     NmsLayout L;
     const int ccs = nms_champ_cs(radius, n_cap, planes);
@@ -67,8 +74,25 @@ __host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_
     L.gh = (H + cs - 1) / cs; if (L.gh < 1) L.gh = 1;
     L.ncell = L.gw * L.gh;
     L.cgw = L.gw + 2 * L.R;
+    L.mask = nms_mask_ok(W, H, radius, n_cap, planes, allow_mask) ? 1 : 0;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    if (L.mask) { // per padded cell: alive word, three score planes, champion key; per frame: open-cell lists, the accepted points' keys
+        const size_t npc = (size_t)L.cgw * (L.gh + 2 * L.R);
+        L.off_cellstart = L.off_cellfill = L.off_cellund = L.off_rec = 0;
+        L.off_counters = take(64);
+        L.off_accflag = take(n_cap > (1 << 20) ? (size_t)n_cap : 0); // only the output order of > 1M raw hits uses it
+        L.off_alive = take(npc * 8);
+        L.off_planes = take(npc * 24);
+        L.off_champ = take(npc * 4);
+        L.off_listA = take((size_t)L.ncell * 4);
+        L.off_listB = take((size_t)L.ncell * 4);
+        L.off_sortkeys = take((size_t)L.ncell * 8); // at most one accepted point per cell
+        L.off_disk = take((size_t)(2 * L.R + 1) * (2 * L.R + 1) * 64 * 8);
+        L.total = o;
+        return L;
+    }
+    L.off_alive = L.off_planes = L.off_disk = 0;
     L.off_cellstart = take((size_t)(L.ncell + 1) * 4);
     L.off_cellfill = take((size_t)(L.ncell + 1) * 4);
     L.off_cellund = take((size_t)(L.ncell + 1) * 4);
@@ -784,6 +808,294 @@ __global__ __launch_bounds__(256) void k_nms_push(NmsLayout L, int radius, int r
     }
 }
 
+// ---- mask rounds (L.mask): champion rounds for 8-pixel cells (r = 10..21, the default r = 16) without per-hit records.
+// An 8x8 cell IS one 64-bit word (bit = 8 * row + column): per padded cell the workspace holds
+//     alive   the hits still undecided (plus the accepted one, if any: it stays visible to its neighbours)
+//     planes  the three FAST score-bit planes of the cell (read-only after setup)
+//     ent     the cell's champion as a 32-bit key (score level, then raster position), bit 31 = "accepted"
+// and per radius one table disk[offset][position] = the pixels of the neighbouring cell at `offset` within r of in-cell
+// position `position`.  Everything a round needs is then register arithmetic on coalesced 8-byte loads:
+//     champion of a cell      = lowest set bit of (alive & highest non-empty score level)
+//     "better than me" there  = (levels above mine) | (my level & raster-earlier pixels)
+//     blockers of a champion  = alive[n] & disk & better   over the neighbouring cells n whose champion is better
+//     suppression             = atomicAnd(alive[n], ~disk)  (no return value: fire and forget)
+// The champion grid is only a FILTER (an entry is never below the cell's true champion, so a cell whose entry is not
+// better than me holds nothing better); exactness comes from the masks.  Entries may therefore be stale, and one
+// launch per round does both the refresh of a cell's own entry and the test.  A bit cleared while a round is running
+// is a suppressed point, which can never block anybody, so reading alive words mid-round is safe in both directions.
+// No sort of the hits into cells, no records: setup is one pass over the FAST planes.
+constexpr uint32_t MK_FLAG = 0x80000000u, MK_KEY = 0x7FFFFFFFu;
+
+struct MaskPtrs {
+    unsigned long long *alive, *pl0, *pl1, *pl2;
+    uint32_t *ent, *counters, *listA, *listB;
+    unsigned long long *sortkeys;
+};
+
+__device__ __forceinline__ MaskPtrs mask_ptrs(unsigned char *ws, const NmsLayout &L)
+{
+    MaskPtrs M;
+    const size_t npc = (size_t)L.cgw * (L.gh + 2 * L.R);
+    M.alive = reinterpret_cast<unsigned long long *>(ws + L.off_alive);
+    M.pl0 = reinterpret_cast<unsigned long long *>(ws + L.off_planes);
+    M.pl1 = M.pl0 + npc;
+    M.pl2 = M.pl1 + npc;
+    M.ent = reinterpret_cast<uint32_t *>(ws + L.off_champ);
+    M.counters = reinterpret_cast<uint32_t *>(ws + L.off_counters);
+    M.listA = reinterpret_cast<uint32_t *>(ws + L.off_listA);
+    M.listB = reinterpret_cast<uint32_t *>(ws + L.off_listB);
+    M.sortkeys = reinterpret_cast<unsigned long long *>(ws + L.off_sortkeys);
+    return M;
+}
+
+// key: larger = better; score code 1..5 (score - 11), then raster position ascending (== raster rank ascending)
+__device__ __forceinline__ uint32_t mask_key(int code, int x, int y) { return ((uint32_t)code << 28) | (0x0FFFFFFFu - (((uint32_t)y << 14) | (uint32_t)x)); }
+
+__device__ __forceinline__ uint32_t mask_champ(unsigned long long a, unsigned long long A0, unsigned long long A1, unsigned long long A2,
+                                               int cx, int cy)
+{
+    if (!a) return 0u;
+    // codes (planes A2 A1 A0): 5 = 101, 4 = 100, 3 = 011, 2 = 010, 1 = 001
+    unsigned long long m = a & A2 & A0;
+    int code = 5;
+    if (!m) { m = a & A2; code = 4; }
+    if (!m) { m = a & A1 & A0; code = 3; }
+    if (!m) { m = a & A1; code = 2; }
+    if (!m) { m = a; code = 1; }
+    const int b = __builtin_ctzll(m);
+    return mask_key(code, cx * 8 + (b & 7), cy * 8 + (b >> 3));
+}
+
+// alive words are changed by L2 atomics; the tail kernel reads them again after a block barrier, so the load goes to L2
+__device__ __forceinline__ unsigned long long load_alive(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int RR>
+__global__ __launch_bounds__(256) void k_nmsm_setup(const unsigned long long *__restrict__ seg_all,
+                                                    const uint32_t *__restrict__ segoff_all, const int32_t *__restrict__ n_raw_all,
+                                                    int W, int H, int ntx, int n_cap, int radius, NmsLayout L,
+                                                    unsigned char *ws_all, size_t ws_stride)
+{
+    constexpr int ND = 2 * RR + 1;
+    const int f = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int cgh = L.gh + 2 * RR, npc = L.cgw * cgh;
+    if (f == 0) { // the disk table of this radius (frame 0's copy serves every frame)
+        unsigned long long *disk = reinterpret_cast<unsigned long long *>(ws_all + L.off_disk);
+        const int r2 = radius * radius;
+        for (int t = q; t < ND * ND * 64; t += gridDim.x * 256) {
+            const int o = t >> 6, pos = t & 63, ux = pos & 7, uy = pos >> 3;
+            const int dx = o % ND - RR, dy = o / ND - RR;
+            unsigned long long m = 0;
+            for (int i = 0; i < 8; i++) {
+                const int ddy = dy * 8 + i - uy, rem = r2 - ddy * ddy;
+                if (rem < 0) continue;
+                int hw = (int)sqrtf((float)rem);
+                while ((hw + 1) * (hw + 1) <= rem) hw++;
+                while (hw * hw > rem) hw--;
+                int lo = ux - dx * 8 - hw, hi = ux - dx * 8 + hw; // columns j of the neighbouring cell with |dx*8 + j - ux| <= hw
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > 7 ? 7 : hi;
+                if (lo <= hi) m |= (unsigned long long)(((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u)) << (8 * i);
+            }
+            disk[t] = m;
+        }
+    }
+    if (q >= npc) return;
+    const MaskPtrs M = mask_ptrs(ws_all + (size_t)f * ws_stride, L);
+    if (q < 16) M.counters[q] = 0;
+    const int py = q / L.cgw, px = q - py * L.cgw;
+    const int cx = px - RR, cy = py - RR;
+    if (cx < 0 || cx >= L.gw || cy < 0 || cy >= L.gh) { // border: never alive, never a champion
+        M.alive[q] = 0ull;
+        M.ent[q] = 0u;
+        return;
+    }
+    const int x0 = cx * 8, tx = x0 >> 6, bo = x0 & 63;
+    const int y0 = cy * 8, y1 = (y0 + 8 < H) ? y0 + 8 : H;
+    const size_t nseg = (size_t)H * ntx;
+    const unsigned long long *seg = seg_all + (size_t)f * nseg * 4;
+    const bool over = n_raw_all[f] > n_cap; // hits past the raw capacity are dropped everywhere (PGX_E_CAPACITY is raised)
+    unsigned long long A0 = 0, A1 = 0, A2 = 0;
+    ulonglong2 rp8[8];
+    unsigned long long rb8[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { // all loads first
+        const bool ok = y0 + i < y1;
+        const size_t si = (size_t)(ok ? y0 + i : y0) * ntx + tx;
+        rp8[i] = *reinterpret_cast<const ulonglong2 *>(seg + si * 4);
+        rb8[i] = seg[si * 4 + 2];
+        if (!ok) { rp8[i] = make_ulonglong2(0ull, 0ull); rb8[i] = 0ull; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const unsigned long long any = rp8[i].x | rp8[i].y | rb8[i];
+        uint32_t keep = (uint32_t)(any >> bo) & 0xFFu;
+        if (over && keep) { // keep the first n_cap - base hits of the row slice (raster ranks below n_cap)
+            const uint32_t base = segoff_all[(size_t)f * nseg + (size_t)(y0 + i) * ntx + tx] + (uint32_t)__popcll(any & ((1ull << bo) - 1ull));
+            const uint32_t room = base < (uint32_t)n_cap ? (uint32_t)n_cap - base : 0u;
+            while ((uint32_t)__popc(keep) > room) keep &= ~(1u << (31 - __builtin_clz(keep)));
+        }
+        A0 |= ((rp8[i].x >> bo) & (unsigned long long)keep) << (8 * i);
+        A1 |= ((rp8[i].y >> bo) & (unsigned long long)keep) << (8 * i);
+        A2 |= ((rb8[i] >> bo) & (unsigned long long)keep) << (8 * i);
+    }
+    const unsigned long long a = A0 | A1 | A2;
+    M.alive[q] = a;
+    M.pl0[q] = A0; M.pl1[q] = A1; M.pl2[q] = A2;
+    M.ent[q] = mask_champ(a, A0, A1, A2, cx, cy);
+}
+
+struct MaskOut { uint32_t *raw_xy; int32_t *raw_score; const unsigned long long *seg; const uint32_t *segoff; int ntx; };
+
+// One round for 64 cells (lane = cell c, valid when incell); called by whole wavefronts.
+__device__ __forceinline__ uint32_t ent_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ent_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int RR>
+__device__ __forceinline__ void mask_round_wave(const MaskPtrs &M, const NmsLayout &L, const unsigned long long *__restrict__ disk,
+                                                int radius, int c, bool incell, const MaskOut &out)
+{
+    constexpr int ND = 2 * RR + 1, NO = ND * ND;
+    const int lane = threadIdx.x & 63;
+    const int cc = incell ? c : 0;
+    const int cy = cc / L.gw, cx = cc - cy * L.gw;
+    const int pc = (cy + RR) * L.cgw + cx + RR;
+    uint32_t me = incell ? ent_load(M.ent + pc) : 0u;
+    unsigned long long a = incell ? load_alive(M.alive + pc) : 0ull;
+    bool live = false;
+    if (incell) {
+        if (me & MK_FLAG) { // accepted in an earlier round: everything else in the cell is suppressed; close it
+            ent_store(M.ent + pc, 0u);
+            // through the atomic path like every other change of an alive word: a plain store would sit in this XCD's L2
+            // beside words that other XCDs are changing in memory
+            __hip_atomic_store(M.alive + pc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (a == 0ull) {
+            if (me) ent_store(M.ent + pc, 0u);
+        } else {
+            const uint32_t pos = 0x0FFFFFFFu - (me & 0x0FFFFFFFu);
+            const int b = (int)((((pos >> 14) & 7u) << 3) | (pos & 7u));
+            if (me == 0u || !((a >> b) & 1ull)) { // the champion was suppressed: next one
+                me = mask_champ(a, M.pl0[pc], M.pl1[pc], M.pl2[pc], cx, cy);
+                ent_store(M.ent + pc, me);
+            }
+            live = true;
+        }
+    }
+    if (!__any(live)) return;
+    const uint32_t mypos = 0x0FFFFFFFu - (me & 0x0FFFFFFFu);
+    const int mx = (int)(mypos & 0x3FFFu), my = (int)(mypos >> 14);
+    const int ux = mx & 7, uy = my & 7, code = (int)(me >> 28);
+    const int r2 = radius * radius;
+    const unsigned long long rows_below = (1ull << (8 * uy)) - 1ull;
+    const unsigned long long row_mine = 0xFFull << (8 * uy);
+    const unsigned long long *dk = disk + (uy * 8 + ux);
+
+    // the filter: all neighbouring champions, loads issued together; one bit per neighbour that needs the exact test
+    unsigned long long needm = 0ull;
+    {
+        uint32_t e[NO];
+#pragma unroll
+        for (int o = 0; o < NO; o++) {
+            const int dx = o % ND - RR, dy = o / ND - RR;
+            e[o] = (dx == 0 && dy == 0) ? 0u : M.ent[pc + dy * L.cgw + dx]; // plain: a stale entry is an older, higher one
+        }
+#pragma unroll
+        for (int o = 0; o < NO; o++) {
+            const int dx = o % ND - RR, dy = o / ND - RR;
+            // nearest pixel of that cell: if it is farther than r the cell cannot hold a blocker
+            const int ndx = dx > 0 ? dx * 8 - ux : (dx < 0 ? ux - (dx * 8 + 7) : 0);
+            const int ndy = dy > 0 ? dy * 8 - uy : (dy < 0 ? uy - (dy * 8 + 7) : 0);
+            if ((e[o] & MK_KEY) > me && ndx * ndx + ndy * ndy <= r2) needm |= 1ull << o;
+        }
+        if (!live) needm = 0ull;
+    }
+    // "better than me" = score level above mine, or my level and raster-earlier.  With ge_t = pixels of level >= t
+    // (ge5 = p2 & p0, ge4 = p2, ge3 = p2 | (p1 & p0), ge2 = p2 | p1, ge1 = every hit) that is ge(code + 1) | (ge(code) & E);
+    // the level is picked with per-lane all-ones masks, so the step below is straight-line code for the whole wavefront.
+    const unsigned long long s5 = code == 5 ? ~0ull : 0ull, s4 = code == 4 ? ~0ull : 0ull, s3 = code == 3 ? ~0ull : 0ull,
+                             s2 = code == 2 ? ~0ull : 0ull, s1 = code == 1 ? ~0ull : 0ull;
+    bool blocked = false;
+#pragma unroll 1
+    for (int j = 0; j < ND; j++) { // one row of neighbouring cells per step: the loads of a step are issued together
+        const int dy = j - RR, g0 = j * ND;
+        const unsigned long long gm = blocked ? 0ull : (needm >> g0) & ((1ull << ND) - 1ull);
+        if (!__any(gm != 0ull)) continue; // nobody in the wavefront needs this row
+        // Every lane loads the whole row and the need bits are applied afterwards: loads under per-lane predicates
+        // (divergent skips of single cells) gave rare wrong "not blocked" results on gfx950 that were never explained
+        // (DESIGN.md section 4); wave-uniform control flow around full-exec loads has not shown them.
+        const uint32_t prow = (uint32_t)(pc + dy * L.cgw - RR);
+        const unsigned long long *dkr = dk + (size_t)g0 * 64;
+        unsigned long long an[ND], dm[ND], p0[ND], p1[ND], p2[ND];
+#pragma unroll
+        for (int k = 0; k < ND; k++) {
+            an[k] = load_alive(M.alive + prow + k);
+            dm[k] = dkr[k * 64];
+            p0[k] = M.pl0[prow + k]; p1[k] = M.pl1[prow + k]; p2[k] = M.pl2[prow + k];
+        }
+        // raster-earlier pixels of those cells (same score level: the earlier one wins)
+        const unsigned long long Eall = dy < 0 ? ~0ull : 0ull, Erow = dy == 0 ? rows_below : 0ull;
+        unsigned long long hit = 0ull;
+#pragma unroll
+        for (int k = 0; k < ND; k++) {
+            const int dx = k - RR;
+            const unsigned long long E = Eall | Erow | ((dy == 0 && dx < 0) ? row_mine : 0ull);
+            const unsigned long long ge5 = p2[k] & p0[k], ge4 = p2[k], ge3 = p2[k] | (p1[k] & p0[k]), ge2 = p2[k] | p1[k];
+            const unsigned long long above = (ge5 & s4) | (ge4 & s3) | (ge3 & s2) | (ge2 & s1);
+            const unsigned long long mine = (ge5 & s5) | (ge4 & s4) | (ge3 & s3) | (ge2 & s2) | s1;
+            const unsigned long long needk = ((gm >> k) & 1ull) ? ~0ull : 0ull;
+            hit |= an[k] & dm[k] & (above | (mine & E)) & needk;
+        }
+        blocked = blocked || hit != 0ull;
+    }
+    const bool accept = live && !blocked;
+    const unsigned long long acc = __ballot(accept);
+    if (!acc) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&M.counters[2], (uint32_t)__popcll(acc));
+    base = (uint32_t)__shfl((int)base, 0);
+    if (accept) {
+        ent_store(M.ent + pc, me | MK_FLAG);
+        atomicAnd(M.alive + pc, 1ull << (uy * 8 + ux)); // any two points of a cell are within r
+#pragma unroll 1
+        for (int j = 0; j < ND; j++) {
+            const uint32_t prow = (uint32_t)(pc + (j - RR) * L.cgw - RR);
+            unsigned long long d[ND];
+#pragma unroll
+            for (int k = 0; k < ND; k++) d[k] = dk[(j * ND + k) * 64];
+#pragma unroll
+            for (int k = 0; k < ND; k++)
+                if (d[k] && !(j == RR && k == RR)) atomicAnd(M.alive + prow + k, ~d[k]);
+        }
+        // the point's raster rank (its index in the raw lists): offset of its 64-pixel row segment + hits before it there
+        const size_t si = (size_t)my * out.ntx + (mx >> 6);
+        const ulonglong2 s01 = *reinterpret_cast<const ulonglong2 *>(out.seg + si * 4);
+        const unsigned long long s2 = out.seg[si * 4 + 2];
+        const uint32_t rank = out.segoff[si] + (uint32_t)__popcll((s01.x | s01.y | s2) & ((1ull << (mx & 63)) - 1ull));
+        const int score = code + 11;
+        M.sortkeys[base + (uint32_t)__popcll(acc & ((1ull << lane) - 1ull))] = sort_key(score, rank);
+        out.raw_xy[rank] = ((uint32_t)my << 16) | (uint32_t)mx;
+        out.raw_score[rank] = score;
+    }
+}
+
+template <int RR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_nmsm_round(NmsLayout L, int radius, unsigned char *ws_all, size_t ws_stride,
+                                                    uint32_t *raw_xy_all, int32_t *raw_score_all, int n_cap,
+                                                    const unsigned long long *__restrict__ seg_all,
+                                                    const uint32_t *__restrict__ segoff_all, int H, int ntx)
+{
+    const int f = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const MaskPtrs M = mask_ptrs(ws_all + (size_t)f * ws_stride, L);
+    const size_t nseg = (size_t)H * ntx;
+    const MaskOut out{raw_xy_all + (size_t)f * n_cap, raw_score_all + (size_t)f * n_cap, seg_all + (size_t)f * nseg * 4,
+                      segoff_all + (size_t)f * nseg, ntx};
+    mask_round_wave<RR>(M, L, reinterpret_cast<const unsigned long long *>(ws_all + L.off_disk), radius, c, c < L.ncell, out);
+}
+
 __device__ void bitonic_sort_u64(unsigned long long *keys, uint32_t n2p)
 {
     const uint32_t tid = threadIdx.x, nth = blockDim.x;
@@ -828,6 +1140,124 @@ __device__ __forceinline__ bool tail_suppressed(const NmsPtrs &P, const NmsLayou
         if ((o.w == ST_NEW || o.w >= ST_ACCEPTED) && within(o.x, me.x, r2)) return true;
     }
     return false;
+}
+
+// Output order of a frame's accepted points (their keys were appended to P.sortkeys as they were accepted); called by the
+// whole 1024-thread workgroup of a tail kernel.
+__device__ __forceinline__ void tail_order(const NmsPtrs &P, const NmsLayout &L, int radius, int n, const int32_t *raw_score,
+                                           uint32_t *order, int32_t *n_kept_all, int f, int kp_cap, int kp_soft, int *status,
+                                           unsigned long long *lds_keys, uint32_t *wsum /*[16]*/, uint32_t *sh_cnt_p, int *sh_max_p)
+{
+    const int tid = threadIdx.x;
+    uint32_t &sh_cnt = *sh_cnt_p;
+    int &sh_max = *sh_max_p;
+    // ---- the accepted points' keys (score descending, input index ascending) were appended as they were
+    //      accepted; only the degenerate r < 0 case ("distance > r" is always true) gathers everything here
+    __syncthreads();
+    if (radius < 0) {
+        if (tid == 0) sh_cnt = 0;
+        __syncthreads();
+        for (int p = tid; p < n; p += NT) P.sortkeys[atomicAdd(&sh_cnt, 1u)] = sort_key(raw_score[p], (uint32_t)p);
+        __syncthreads();
+    } else {
+        if (tid == 0) sh_cnt = P.counters[2];
+        __syncthreads();
+    }
+    const uint32_t nacc = sh_cnt;
+    const uint32_t n2p = [](uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }(nacc > 1 ? nacc : 1);
+    const uint32_t nw = ((uint32_t)n + 63u) / 64u * 2u;        // 32-bit bitmap words for the raster ranks of one score level
+    if (L.champ && radius >= 0 && nw <= SORT_LDS_MAX * 2) {
+        // FAST scores are 12..16 and the input index is the raster rank, so the output order is "level by
+        // level, rank ascending": one bitmap of ranks per level in LDS, a popcount scan, and every set bit
+        // knows its place.  No comparison sort.
+        uint32_t *bm = reinterpret_cast<uint32_t *>(lds_keys);
+        const uint32_t lp = (SORT_LDS_MAX * 2) / nw < 5u ? (SORT_LDS_MAX * 2) / nw : 5u; // levels per pass
+        const int lane = tid & 63, wv = tid >> 6;
+        uint32_t base = 0;
+        for (int lev_hi = 16; lev_hi >= 12; lev_hi -= (int)lp) {
+            const uint32_t tw = lp * nw;
+            __syncthreads();
+            for (uint32_t i = tid; i < tw; i += NT) bm[i] = 0u;
+            __syncthreads();
+            for (uint32_t i = tid; i < nacc; i += NT) {
+                const unsigned long long k = P.sortkeys[i];
+                const int sc = (int)(~(uint32_t)(k >> 32) ^ 0x80000000u);
+                const uint32_t idx = (uint32_t)k;
+                const int slot = lev_hi - sc;
+                if (slot >= 0 && slot < (int)lp && sc >= 12) atomicOr(&bm[(uint32_t)slot * nw + (idx >> 5)], 1u << (idx & 31u));
+            }
+            __syncthreads();
+            // each wavefront owns a contiguous span of words (rows of 64, lanes on consecutive words)
+            const uint32_t rows = (tw + 63u) / 64u, rpw = (rows + NT / 64 - 1) / (NT / 64);
+            const uint32_t r0 = (uint32_t)wv * rpw, r1 = r0 + rpw < rows ? r0 + rpw : rows;
+            uint32_t cnt = 0;
+            for (uint32_t r = r0; r < r1; r++) { const uint32_t w = r * 64u + lane; cnt += w < tw ? (uint32_t)__popc(bm[w]) : 0u; }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
+            if (lane == 0) wsum[wv] = cnt;
+            __syncthreads();
+            uint32_t run = base, tot = 0;
+            for (int w = 0; w < NT / 64; w++) { const uint32_t v = wsum[w]; if (w < wv) run += v; tot += v; }
+            for (uint32_t r = r0; r < r1; r++) {
+                const uint32_t w = r * 64u + lane;
+                uint32_t bits = w < tw ? bm[w] : 0u;
+                const uint32_t c = (uint32_t)__popc(bits);
+                uint32_t incl = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += t; }
+                uint32_t o = run + incl - c;
+                const uint32_t wl = w % nw; // word inside its level
+                while (bits) {
+                    const int b = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    if (o < (uint32_t)kp_cap) order[o] = wl * 32u + (uint32_t)b;
+                    o++;
+                }
+                run += (uint32_t)__shfl((int)incl, 63);
+            }
+            base += tot;
+        }
+    } else if (n2p <= SORT_LDS_MAX) {
+        for (uint32_t i = tid; i < n2p; i += NT) lds_keys[i] = i < nacc ? P.sortkeys[i] : ~0ull;
+        bitonic_sort_u64(lds_keys, n2p);
+        for (uint32_t i = tid; i < nacc && i < (uint32_t)kp_cap; i += NT) order[i] = (uint32_t)lds_keys[i];
+    } else {
+        // large survivor sets: one stable compaction pass per distinct score, highest first
+        for (int i = tid; i < n; i += NT) P.accflag[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < nacc; i += NT) P.accflag[(uint32_t)P.sortkeys[i]] = 1;
+        __syncthreads();
+        const int per = (n + NT - 1) / NT;
+        const int i0 = tid * per, i1 = (i0 + per < n) ? i0 + per : n;
+        uint32_t base = 0;
+        long long bound = (long long)INT32_MAX + 1;
+        while (true) {
+            if (tid == 0) sh_max = INT32_MIN;
+            __syncthreads();
+            int lm = INT32_MIN;
+            bool have = false;
+            for (int i = i0; i < i1; i++)
+                if (P.accflag[i] && (long long)raw_score[i] < bound) { int s = raw_score[i]; if (!have || s > lm) lm = s; have = true; }
+            if (have) atomicMax(&sh_max, lm);
+            __syncthreads();
+            const int m = sh_max;
+            uint32_t cnt = 0;
+            for (int i = i0; i < i1; i++) cnt += (P.accflag[i] && raw_score[i] == m && (long long)m < bound) ? 1u : 0u;
+            uint32_t ex;
+            const uint32_t tot = block_excl_scan(cnt, &ex, wsum);
+            if (tot == 0) break;
+            uint32_t o = base + ex;
+            for (int i = i0; i < i1; i++)
+                if (P.accflag[i] && raw_score[i] == m) { if (o < (uint32_t)kp_cap) order[o] = (uint32_t)i; o++; }
+            base += tot;
+            bound = m;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        n_kept_all[f] = (int32_t)(nacc < (uint32_t)kp_cap ? nacc : (uint32_t)kp_cap);
+        if (nacc > (uint32_t)kp_cap && !kp_soft) atomicOr(status, (int)PGX_ST_KP_CAP); // a soft limit cuts the list silently
+    }
 }
 
 __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *raw_score_all,
@@ -941,118 +1371,87 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *raw_score_all,
         }
     }
 
-    // ---- the accepted points' keys (score descending, input index ascending) were appended as they were
-    //      accepted; only the degenerate r < 0 case ("distance > r" is always true) gathers everything here
-    __syncthreads();
-    if (radius < 0) {
+    tail_order(P, L, radius, n, raw_score, order, n_kept_all, f, kp_cap, kp_soft, status, lds_keys, wsum, &sh_cnt, &sh_max);
+}
+
+// mask rounds continued by one workgroup per frame on a compact list of the cells whose champion entry is not zero yet
+// (open cells, plus closed ones that still have to take their stale entry down), a block barrier in place of the kernel
+// boundary; then the output order.
+template <int RR>
+__global__ __launch_bounds__(NT) void k_nmsm_tail(const int32_t *raw_score_all, const int32_t *__restrict__ n_raw_all, int n_cap,
+                                                  NmsLayout L, int radius, unsigned char *ws_all, size_t ws_stride,
+                                                  uint32_t *__restrict__ order_all, int32_t *__restrict__ n_kept_all, int kp_cap,
+                                                  int *status, uint32_t *raw_xy_out, int32_t *raw_score_out, int kp_soft,
+                                                  const unsigned long long *seg_all, const uint32_t *segoff_all, int H, int ntx)
+{
+    extern __shared__ unsigned long long lds_keys[];
+    __shared__ uint32_t wsum[NT / 64];
+    __shared__ uint32_t sh_cnt;
+    __shared__ int sh_max;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n = clamp_n(n_raw_all, f, n_cap);
+    if (n == 0) {
+        if (tid == 0) n_kept_all[f] = 0;
+        return;
+    }
+    NmsPtrs P = nms_ptrs(ws_all + (size_t)f * ws_stride, L);
+    {
+        const MaskPtrs M = mask_ptrs(ws_all + (size_t)f * ws_stride, L);
+        const unsigned long long *disk = reinterpret_cast<const unsigned long long *>(ws_all + L.off_disk);
+        const size_t nseg = (size_t)H * ntx;
+        const MaskOut out{raw_xy_out + (size_t)f * n_cap, raw_score_out + (size_t)f * n_cap, seg_all + (size_t)f * nseg * 4,
+                          segoff_all + (size_t)f * nseg, ntx};
         if (tid == 0) sh_cnt = 0;
         __syncthreads();
-        for (int p = tid; p < n; p += NT) P.sortkeys[atomicAdd(&sh_cnt, 1u)] = sort_key(raw_score[p], (uint32_t)p);
+        for (int c = tid; c < L.ncell; c += NT) {
+            const int cy = c / L.gw, cx = c - cy * L.gw;
+            if (M.ent[(cy + RR) * L.cgw + cx + RR] != 0u) M.listA[atomicAdd(&sh_cnt, 1u)] = (uint32_t)c;
+        }
         __syncthreads();
-    } else {
-        if (tid == 0) sh_cnt = P.counters[2];
+        uint32_t *cur = M.listA, *nxt = M.listB;
+        int n_live = (int)sh_cnt;
+        const int n_open0 = n_live;
+        int rounds = 0;
         __syncthreads();
-    }
-    const uint32_t nacc = sh_cnt;
-    const uint32_t n2p = [](uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }(nacc > 1 ? nacc : 1);
-    const uint32_t nw = ((uint32_t)n + 63u) / 64u * 2u;        // 32-bit bitmap words for the raster ranks of one score level
-    if (L.champ && radius >= 0 && nw <= SORT_LDS_MAX * 2) {
-        // FAST scores are 12..16 and the input index is the raster rank, so the output order is "level by
-        // level, rank ascending": one bitmap of ranks per level in LDS, a popcount scan, and every set bit
-        // knows its place.  No comparison sort.
-        uint32_t *bm = reinterpret_cast<uint32_t *>(lds_keys);
-        const uint32_t lp = (SORT_LDS_MAX * 2) / nw < 5u ? (SORT_LDS_MAX * 2) / nw : 5u; // levels per pass
-        const int lane = tid & 63, wv = tid >> 6;
-        uint32_t base = 0;
-        for (int lev_hi = 16; lev_hi >= 12; lev_hi -= (int)lp) {
-            const uint32_t tw = lp * nw;
+        while (n_live > 0) {
+            for (int base = 0; base < n_live; base += NT) { // whole wavefronts: lane = one listed cell
+                const int i = base + tid;
+                const bool in = i < n_live;
+                const int c = in ? (int)cur[i] : 0;
+                mask_round_wave<RR>(M, L, disk, radius, c, in, out);
+            }
+            if (tid == 0) sh_cnt = 0;
             __syncthreads();
-            for (uint32_t i = tid; i < tw; i += NT) bm[i] = 0u;
-            __syncthreads();
-            for (uint32_t i = tid; i < nacc; i += NT) {
-                const unsigned long long k = P.sortkeys[i];
-                const int sc = (int)(~(uint32_t)(k >> 32) ^ 0x80000000u);
-                const uint32_t idx = (uint32_t)k;
-                const int slot = lev_hi - sc;
-                if (slot >= 0 && slot < (int)lp && sc >= 12) atomicOr(&bm[(uint32_t)slot * nw + (idx >> 5)], 1u << (idx & 31u));
+            for (int i = tid; i < n_live; i += NT) {
+                const uint32_t c = cur[i];
+                const int cy = (int)c / L.gw, cx = (int)c - cy * L.gw;
+                if (M.ent[(cy + RR) * L.cgw + cx + RR] != 0u) nxt[atomicAdd(&sh_cnt, 1u)] = c; // order inside the list is irrelevant
             }
             __syncthreads();
-            // each wavefront owns a contiguous span of words (rows of 64, lanes on consecutive words)
-            const uint32_t rows = (tw + 63u) / 64u, rpw = (rows + NT / 64 - 1) / (NT / 64);
-            const uint32_t r0 = (uint32_t)wv * rpw, r1 = r0 + rpw < rows ? r0 + rpw : rows;
-            uint32_t cnt = 0;
-            for (uint32_t r = r0; r < r1; r++) { const uint32_t w = r * 64u + lane; cnt += w < tw ? (uint32_t)__popc(bm[w]) : 0u; }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
-            if (lane == 0) wsum[wv] = cnt;
+            n_live = (int)sh_cnt;
+            { uint32_t *t = cur; cur = nxt; nxt = t; }
             __syncthreads();
-            uint32_t run = base, tot = 0;
-            for (int w = 0; w < NT / 64; w++) { const uint32_t v = wsum[w]; if (w < wv) run += v; tot += v; }
-            for (uint32_t r = r0; r < r1; r++) {
-                const uint32_t w = r * 64u + lane;
-                uint32_t bits = w < tw ? bm[w] : 0u;
-                const uint32_t c = (uint32_t)__popc(bits);
-                uint32_t incl = c;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += t; }
-                uint32_t o = run + incl - c;
-                const uint32_t wl = w % nw; // word inside its level
-                while (bits) {
-                    const int b = __builtin_ctz(bits);
-                    bits &= bits - 1;
-                    if (o < (uint32_t)kp_cap) order[o] = wl * 32u + (uint32_t)b;
-                    o++;
-                }
-                run += (uint32_t)__shfl((int)incl, 63);
+            // with fresh entries every round accepts the best open point; an entry may be one round stale
+            if (++rounds > 2 * n_open0 + 16) {
+                if (tid == 0) atomicOr(status, (int)PGX_ST_INTERNAL);
+                break;
             }
-            base += tot;
-        }
-    } else if (n2p <= SORT_LDS_MAX) {
-        for (uint32_t i = tid; i < n2p; i += NT) lds_keys[i] = i < nacc ? P.sortkeys[i] : ~0ull;
-        bitonic_sort_u64(lds_keys, n2p);
-        for (uint32_t i = tid; i < nacc && i < (uint32_t)kp_cap; i += NT) order[i] = (uint32_t)lds_keys[i];
-    } else {
-        // large survivor sets: one stable compaction pass per distinct score, highest first
-        for (int i = tid; i < n; i += NT) P.accflag[i] = 0;
-        __syncthreads();
-        for (uint32_t i = tid; i < nacc; i += NT) P.accflag[(uint32_t)P.sortkeys[i]] = 1;
-        __syncthreads();
-        const int per = (n + NT - 1) / NT;
-        const int i0 = tid * per, i1 = (i0 + per < n) ? i0 + per : n;
-        uint32_t base = 0;
-        long long bound = (long long)INT32_MAX + 1;
-        while (true) {
-            if (tid == 0) sh_max = INT32_MIN;
-            __syncthreads();
-            int lm = INT32_MIN;
-            bool have = false;
-            for (int i = i0; i < i1; i++)
-                if (P.accflag[i] && (long long)raw_score[i] < bound) { int s = raw_score[i]; if (!have || s > lm) lm = s; have = true; }
-            if (have) atomicMax(&sh_max, lm);
-            __syncthreads();
-            const int m = sh_max;
-            uint32_t cnt = 0;
-            for (int i = i0; i < i1; i++) cnt += (P.accflag[i] && raw_score[i] == m && (long long)m < bound) ? 1u : 0u;
-            uint32_t ex;
-            const uint32_t tot = block_excl_scan(cnt, &ex, wsum);
-            if (tot == 0) break;
-            uint32_t o = base + ex;
-            for (int i = i0; i < i1; i++)
-                if (P.accflag[i] && raw_score[i] == m) { if (o < (uint32_t)kp_cap) order[o] = (uint32_t)i; o++; }
-            base += tot;
-            bound = m;
-            __syncthreads();
         }
     }
-    if (tid == 0) {
-        n_kept_all[f] = (int32_t)(nacc < (uint32_t)kp_cap ? nacc : (uint32_t)kp_cap);
-        if (nacc > (uint32_t)kp_cap && !kp_soft) atomicOr(status, (int)PGX_ST_KP_CAP); // a soft limit cuts the list silently
-    }
+    __syncthreads();
+    tail_order(P, L, radius, n, raw_score_all + (size_t)f * n_cap, order_all + (size_t)f * kp_cap, n_kept_all, f, kp_cap, kp_soft,
+               status, lds_keys, wsum, &sh_cnt, &sh_max);
 }
 
 } // namespace
 
-size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap, bool planes) { return nms_layout(W, H, radius, n_cap, planes).total; }
+static bool mask_allowed() // developer A/B switch: PGX_NMS_MASK=0 sends 8-pixel cells through the record-based champion rounds
+{
+    static const bool v = [] { const char *e = getenv("PGX_NMS_MASK"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
+size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap, bool planes) { return nms_layout(W, H, radius, n_cap, planes, mask_allowed()).total; }
 
 bool pgx_nms_fills_raw_lists(int W, int H, int radius, int n_cap) { return radius >= 0 && nms_layout(W, H, radius, n_cap, true).champ != 0; }
 
@@ -1076,6 +1475,12 @@ void nms_setup(const NmsLaunch &a)
     const dim3 pgrid((a.n_cap + 255) / 256, a.F);
     const dim3 bgrid((L.ncell + 255) / 256, a.F);
     const int ntx = (a.W + 63) / 64;
+    if (L.mask) {
+        const dim3 sgrid((L.cgw * (L.gh + 2 * L.R) + 255) / 256, a.F);
+        if (L.R <= 2) hipLaunchKernelGGL(k_nmsm_setup<2>, sgrid, dim3(256), 0, s, a.seg, a.segoff, a.n_raw, a.W, a.H, ntx, a.n_cap, a.radius, L, a.ws, a.ws_stride);
+        else hipLaunchKernelGGL(k_nmsm_setup<3>, sgrid, dim3(256), 0, s, a.seg, a.segoff, a.n_raw, a.W, a.H, ntx, a.n_cap, a.radius, L, a.ws, a.ws_stride);
+        return;
+    }
     hipLaunchKernelGGL(k_nms_zero, dim3((L.ncell + 256) / 256, a.F), dim3(256), 0, s, L, a.ws, a.ws_stride);
     if (a.planes && L.cs == 8) hipLaunchKernelGGL(k_nms_bin_planes8<0>, bgrid, dim3(256), 0, s, a.seg, a.segoff, a.W, a.H, ntx, a.n_cap, L, a.ws, a.ws_stride);
     else if (a.planes) hipLaunchKernelGGL(k_nms_bin_planes<0>, bgrid, dim3(256), 0, s, a.seg, a.segoff, a.W, a.H, ntx, a.n_cap, L, a.ws, a.ws_stride);
@@ -1094,8 +1499,12 @@ void nms_rounds(const NmsLaunch &a, int r0, int n)
     hipStream_t s = a.s;
     const dim3 bgrid((L.ncell + 255) / 256, a.F);
     const dim3 cgrid((L.ncell + 3) / 4, a.F);
+    const int ntx = (a.W + 63) / 64;
     for (int r = r0; r < r0 + n; r++) {
-        if (L.champ) {
+        if (L.mask) {
+            if (L.R <= 2) hipLaunchKernelGGL(k_nmsm_round<2>, bgrid, dim3(256), 0, s, L, a.radius, a.ws, a.ws_stride, a.raw_xy, a.raw_score, a.n_cap, a.seg, a.segoff, a.H, ntx);
+            else hipLaunchKernelGGL(k_nmsm_round<3>, bgrid, dim3(256), 0, s, L, a.radius, a.ws, a.ws_stride, a.raw_xy, a.raw_score, a.n_cap, a.seg, a.segoff, a.H, ntx);
+        } else if (L.champ) {
             if (r > 0) hipLaunchKernelGGL(k_nms_champ, bgrid, dim3(256), 0, s, L, a.ws, a.ws_stride);
             if (L.R <= 2) {
                 if (r <= 1) hipLaunchKernelGGL((k_nms_phase_c<2, true>), bgrid, dim3(256), 0, s, L, a.radius, r, a.ws, a.ws_stride, a.raw_xy, a.raw_score, a.n_cap);
@@ -1117,7 +1526,18 @@ void nms_finish(const NmsLaunch &a, int round0)
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nms_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(SORT_LDS_MAX * 8));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nmsm_tail<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(SORT_LDS_MAX * 8));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nmsm_tail<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(SORT_LDS_MAX * 8));
         attr_set = true;
+    }
+    if (a.L.mask) {
+        auto kern = a.L.R <= 2 ? &k_nmsm_tail<2> : &k_nmsm_tail<3>;
+        hipLaunchKernelGGL(kern, dim3(a.F), dim3(NT), SORT_LDS_MAX * 8, a.s, a.raw_score, a.n_raw, a.n_cap, a.L, a.radius, a.ws,
+                           a.ws_stride, a.order, a.n_kept, a.kp_cap, a.status, a.raw_xy, a.raw_score, a.kp_soft, a.seg, a.segoff, a.H,
+                           (a.W + 63) / 64);
+        return;
     }
     hipLaunchKernelGGL(k_nms_tail, dim3(a.F), dim3(NT), SORT_LDS_MAX * 8, a.s, a.raw_score, a.n_raw, a.n_cap, a.L, a.radius, a.ws,
                        a.ws_stride, a.order, a.n_kept, a.kp_cap, a.status, round0, a.raw_xy, a.raw_score, a.kp_soft);
@@ -1132,7 +1552,7 @@ NmsLaunch nms_args(hipStream_t s, uint32_t *raw_xy, int32_t *raw_score, const in
     a.radius = radius; a.ws = reinterpret_cast<unsigned char *>(wsv); a.ws_stride = ws_stride; a.order = order;
     a.n_kept = n_kept; a.kp_cap = kp_cap; a.status = status; a.seg = seg; a.segoff = segoff;
     const bool have_planes = seg && segoff;
-    a.L = nms_layout(W, H, radius, n_cap, have_planes);
+    a.L = nms_layout(W, H, radius, n_cap, have_planes, mask_allowed());
     a.planes = have_planes && (a.L.cs == 8 || a.L.cs == 16 || a.L.cs == 32 || a.L.cs == 64);
     return a;
 }
@@ -1192,3 +1612,4 @@ hipError_t pgx_launch_nms_sync(hipStream_t s, const uint32_t *raw_xy, const int3
     nms_finish(a, r0);
     return hipGetLastError();
 }
+

@@ -364,3 +364,44 @@ def test_two_and_three_ranks_sharing_this_gpu_equal_one_rank(engine):
             assert (d == rdesc).all() and (o == rout).all(), (world, rank)
     engine.set_stream(0)
     engine.set_capacity(1 << 17, 1 << 20)
+
+
+@pytest.mark.parametrize("radius", [16, 12, 21])
+def test_detect_batch_every_frame_repeated(engine, radius):
+    """NMS order-independence under load: 8 full-size frames per call, three calls, EVERY frame of every call against the
+    literal oracle (the mask rounds of k_nms.hip decide cells concurrently across the whole chip; r = 16/12 reach 2 cells,
+    r = 21 reaches 3)."""
+    W, H, F, CAP = 1920, 1080, 8, 8192
+    pairs = pg.make_brief_pairs(0, 50, 256)
+    dmap = pg.build_dewarp_map(W, H, [3e-4, 1e-7, 0, 0, 0])
+    engine.set_brief_pairs(pairs)
+    engine.set_detect_params(T, radius)
+    engine.set_capacity(1 << 18, CAP)
+    engine.set_dewarp_map(dmap)
+    base = synth.make_frame(W, H, seed=4321, n_shapes=20000)
+    d_base = torch.from_numpy(base).to(DEV)
+    d_frames = torch.empty((F, H, W, 4), dtype=torch.uint16, device=DEV)
+    for i in range(F):
+        d_frames.view(torch.int64)[i] = torch.roll(d_base.view(torch.int64), shifts=(i % H, (3 * i) % W), dims=(0, 1))
+    d_kp = torch.zeros((F, CAP, 4), dtype=torch.int32, device=DEV)
+    d_desc = torch.zeros((F, CAP, 8), dtype=torch.int32, device=DEV)
+    d_cnt = torch.zeros((F,), dtype=torch.int32, device=DEV)
+    d_nraw = torch.zeros((F,), dtype=torch.int32, device=DEV)
+    torch.cuda.synchronize()
+    frames_h = d_frames.cpu().numpy()
+    expect = []
+    for f in range(F):
+        g = cref.gray(cref.apply_distortion(frames_h[f], dmap))
+        raw = cref.detect(g, T)
+        expect.append(raw[cref.nms(raw, radius)])
+    for rep in range(3):
+        engine.detect_batch_dev(d_frames.data_ptr(), F, W, H, d_kp.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(),
+                                d_nraw.data_ptr(), CAP)
+        engine.check_status()
+        cnt = d_cnt.cpu().numpy()
+        kp = d_kp.cpu().numpy()
+        for f in range(F):
+            kept = expect[f]
+            assert cnt[f] == len(kept), (rep, f, cnt[f], len(kept))
+            assert (kp[f, :cnt[f], 0] == kept["x"]).all() and (kp[f, :cnt[f], 1] == kept["y"]).all(), (rep, f)
+            assert (kp[f, :cnt[f], 2] == kept["fast_score"]).all(), (rep, f)
