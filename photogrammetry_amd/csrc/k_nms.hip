@@ -954,69 +954,152 @@ struct MaskOut { uint32_t *raw_xy; int32_t *raw_score; const unsigned long long 
 __device__ __forceinline__ uint32_t ent_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ent_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// ---- pieces of one round, shared by the whole-chip kernel (neighbours staged in LDS) and the tail (neighbours from global)
+
+// own cell at the start of a round: close it if its champion was accepted, take a stale entry down if it ran empty,
+// move on to the next champion if the current one was suppressed.  Returns true when the cell has a champion to test.
+__device__ __forceinline__ bool mask_own(const MaskPtrs &M, int pc, int cx, int cy, bool incell, uint32_t &me, unsigned long long a,
+                                         unsigned long long q0, unsigned long long q1, unsigned long long q2)
+{
+    if (!incell) return false;
+    if (me & MK_FLAG) { // accepted in an earlier round: everything else in the cell is suppressed; close it
+        ent_store(M.ent + pc, 0u);
+        // through the atomic path like every other change of an alive word
+        __hip_atomic_store(M.alive + pc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
+    if (a == 0ull) {
+        if (me) ent_store(M.ent + pc, 0u);
+        return false;
+    }
+    const uint32_t pos = 0x0FFFFFFFu - (me & 0x0FFFFFFFu);
+    const int b = (int)((((pos >> 14) & 7u) << 3) | (pos & 7u));
+    if (me == 0u || !((a >> b) & 1ull)) { // the champion was suppressed: next one
+        me = mask_champ(a, q0, q1, q2, cx, cy);
+        ent_store(M.ent + pc, me);
+    }
+    return true;
+}
+
+// per-lane constants of a champion under test
+struct MaskMe {
+    uint32_t key;
+    int mx, my, ux, uy, code;
+    unsigned long long rows_below, row_mine, s5, s4, s3, s2, s1;
+};
+
+__device__ __forceinline__ MaskMe mask_me(uint32_t me)
+{
+    MaskMe m;
+    m.key = me;
+    const uint32_t mypos = 0x0FFFFFFFu - (me & 0x0FFFFFFFu);
+    m.mx = (int)(mypos & 0x3FFFu); m.my = (int)(mypos >> 14);
+    m.ux = m.mx & 7; m.uy = m.my & 7; m.code = (int)(me >> 28);
+    m.rows_below = (1ull << (8 * m.uy)) - 1ull;
+    m.row_mine = 0xFFull << (8 * m.uy);
+    // "better than me" = score level above mine, or my level and raster-earlier.  With ge_t = pixels of level >= t
+    // (ge5 = p2 & p0, ge4 = p2, ge3 = p2 | (p1 & p0), ge2 = p2 | p1, ge1 = every hit) that is ge(code + 1) | (ge(code) & E);
+    // the level is picked with per-lane all-ones masks, so a step is straight-line code for the whole wavefront.
+    m.s5 = m.code == 5 ? ~0ull : 0ull; m.s4 = m.code == 4 ? ~0ull : 0ull; m.s3 = m.code == 3 ? ~0ull : 0ull;
+    m.s2 = m.code == 2 ? ~0ull : 0ull; m.s1 = m.code == 1 ? ~0ull : 0ull;
+    return m;
+}
+
+// the filter: one bit per neighbouring cell whose champion is better than mine and whose nearest pixel is within r
+template <int RR>
+__device__ __forceinline__ unsigned long long mask_need(const MaskMe &m, const uint32_t *e /*[NO]*/, int r2)
+{
+    constexpr int ND = 2 * RR + 1, NO = ND * ND;
+    unsigned long long needm = 0ull;
+#pragma unroll
+    for (int o = 0; o < NO; o++) {
+        const int dx = o % ND - RR, dy = o / ND - RR;
+        if (dx == 0 && dy == 0) continue;
+        const int ndx = dx > 0 ? dx * 8 - m.ux : (dx < 0 ? m.ux - (dx * 8 + 7) : 0);
+        const int ndy = dy > 0 ? dy * 8 - m.uy : (dy < 0 ? m.uy - (dy * 8 + 7) : 0);
+        if ((e[o] & MK_KEY) > m.key && ndx * ndx + ndy * ndy <= r2) needm |= 1ull << o;
+    }
+    return needm;
+}
+
+// blockers in one neighbouring cell (dx, dy compile-time or uniform): alive & within r & better than me
+__device__ __forceinline__ unsigned long long mask_blockers(const MaskMe &m, int dx, int dy, unsigned long long an, unsigned long long dm,
+                                                            unsigned long long p0, unsigned long long p1, unsigned long long p2)
+{
+    // raster-earlier pixels of that cell (same score level: the earlier one wins)
+    const unsigned long long E = dy < 0 ? ~0ull : (dy > 0 ? 0ull : (m.rows_below | (dx < 0 ? m.row_mine : 0ull)));
+    const unsigned long long ge5 = p2 & p0, ge4 = p2, ge3 = p2 | (p1 & p0), ge2 = p2 | p1;
+    const unsigned long long above = (ge5 & m.s4) | (ge4 & m.s3) | (ge3 & m.s2) | (ge2 & m.s1);
+    const unsigned long long mine = (ge5 & m.s5) | (ge4 & m.s4) | (ge3 & m.s3) | (ge2 & m.s2) | m.s1;
+    return an & dm & (above | (mine & E));
+}
+
+// accept the champions of the lanes with `accept`: stamp, suppress everything within r, emit the output records.
+// Called by whole wavefronts.
+template <int RR>
+__device__ __forceinline__ void mask_accept(const MaskPtrs &M, const NmsLayout &L, const unsigned long long *dk, int pc, const MaskMe &m,
+                                            bool accept, const MaskOut &out)
+{
+    constexpr int ND = 2 * RR + 1;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long acc = __ballot(accept);
+    if (!acc) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&M.counters[2], (uint32_t)__popcll(acc));
+    base = (uint32_t)__shfl((int)base, 0);
+    if (accept) {
+        ent_store(M.ent + pc, m.key | MK_FLAG);
+        atomicAnd(M.alive + pc, 1ull << (m.uy * 8 + m.ux)); // any two points of a cell are within r
+#pragma unroll 1
+        for (int j = 0; j < ND; j++) {
+            const uint32_t prow = (uint32_t)(pc + (j - RR) * L.cgw - RR);
+            unsigned long long d[ND];
+#pragma unroll
+            for (int k = 0; k < ND; k++) d[k] = dk[(j * ND + k) * 64];
+#pragma unroll
+            for (int k = 0; k < ND; k++)
+                if (d[k] && !(j == RR && k == RR)) atomicAnd(M.alive + prow + k, ~d[k]);
+        }
+        // the point's raster rank (its index in the raw lists): offset of its 64-pixel row segment + hits before it there
+        const size_t si = (size_t)m.my * out.ntx + (m.mx >> 6);
+        const ulonglong2 s01 = *reinterpret_cast<const ulonglong2 *>(out.seg + si * 4);
+        const unsigned long long s2 = out.seg[si * 4 + 2];
+        const uint32_t rank = out.segoff[si] + (uint32_t)__popcll((s01.x | s01.y | s2) & ((1ull << (m.mx & 63)) - 1ull));
+        const int score = m.code + 11;
+        M.sortkeys[base + (uint32_t)__popcll(acc & ((1ull << lane) - 1ull))] = sort_key(score, rank);
+        out.raw_xy[rank] = ((uint32_t)m.my << 16) | (uint32_t)m.mx;
+        out.raw_score[rank] = score;
+    }
+}
+
+// One round for 64 cells (lane = cell c, valid when incell), neighbours read from global memory; called by whole
+// wavefronts (the tail kernel's compact lists).
 template <int RR>
 __device__ __forceinline__ void mask_round_wave(const MaskPtrs &M, const NmsLayout &L, const unsigned long long *__restrict__ disk,
                                                 int radius, int c, bool incell, const MaskOut &out)
 {
     constexpr int ND = 2 * RR + 1, NO = ND * ND;
-    const int lane = threadIdx.x & 63;
     const int cc = incell ? c : 0;
     const int cy = cc / L.gw, cx = cc - cy * L.gw;
     const int pc = (cy + RR) * L.cgw + cx + RR;
     uint32_t me = incell ? ent_load(M.ent + pc) : 0u;
-    unsigned long long a = incell ? load_alive(M.alive + pc) : 0ull;
-    bool live = false;
-    if (incell) {
-        if (me & MK_FLAG) { // accepted in an earlier round: everything else in the cell is suppressed; close it
-            ent_store(M.ent + pc, 0u);
-            // through the atomic path like every other change of an alive word: a plain store would sit in this XCD's L2
-            // beside words that other XCDs are changing in memory
-            __hip_atomic_store(M.alive + pc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (a == 0ull) {
-            if (me) ent_store(M.ent + pc, 0u);
-        } else {
-            const uint32_t pos = 0x0FFFFFFFu - (me & 0x0FFFFFFFu);
-            const int b = (int)((((pos >> 14) & 7u) << 3) | (pos & 7u));
-            if (me == 0u || !((a >> b) & 1ull)) { // the champion was suppressed: next one
-                me = mask_champ(a, M.pl0[pc], M.pl1[pc], M.pl2[pc], cx, cy);
-                ent_store(M.ent + pc, me);
-            }
-            live = true;
-        }
-    }
+    const unsigned long long a = incell ? load_alive(M.alive + pc) : 0ull;
+    const bool live = mask_own(M, pc, cx, cy, incell, me, a, M.pl0[pc], M.pl1[pc], M.pl2[pc]);
     if (!__any(live)) return;
-    const uint32_t mypos = 0x0FFFFFFFu - (me & 0x0FFFFFFFu);
-    const int mx = (int)(mypos & 0x3FFFu), my = (int)(mypos >> 14);
-    const int ux = mx & 7, uy = my & 7, code = (int)(me >> 28);
+    const MaskMe m = mask_me(me);
     const int r2 = radius * radius;
-    const unsigned long long rows_below = (1ull << (8 * uy)) - 1ull;
-    const unsigned long long row_mine = 0xFFull << (8 * uy);
-    const unsigned long long *dk = disk + (uy * 8 + ux);
+    const unsigned long long *dk = disk + (m.uy * 8 + m.ux);
 
-    // the filter: all neighbouring champions, loads issued together; one bit per neighbour that needs the exact test
-    unsigned long long needm = 0ull;
+    unsigned long long needm;
     {
-        uint32_t e[NO];
+        uint32_t e[NO]; // all neighbouring champions, loads issued together
 #pragma unroll
         for (int o = 0; o < NO; o++) {
             const int dx = o % ND - RR, dy = o / ND - RR;
             e[o] = (dx == 0 && dy == 0) ? 0u : M.ent[pc + dy * L.cgw + dx]; // plain: a stale entry is an older, higher one
         }
-#pragma unroll
-        for (int o = 0; o < NO; o++) {
-            const int dx = o % ND - RR, dy = o / ND - RR;
-            // nearest pixel of that cell: if it is farther than r the cell cannot hold a blocker
-            const int ndx = dx > 0 ? dx * 8 - ux : (dx < 0 ? ux - (dx * 8 + 7) : 0);
-            const int ndy = dy > 0 ? dy * 8 - uy : (dy < 0 ? uy - (dy * 8 + 7) : 0);
-            if ((e[o] & MK_KEY) > me && ndx * ndx + ndy * ndy <= r2) needm |= 1ull << o;
-        }
-        if (!live) needm = 0ull;
+        needm = live ? mask_need<RR>(m, e, r2) : 0ull;
     }
-    // "better than me" = score level above mine, or my level and raster-earlier.  With ge_t = pixels of level >= t
-    // (ge5 = p2 & p0, ge4 = p2, ge3 = p2 | (p1 & p0), ge2 = p2 | p1, ge1 = every hit) that is ge(code + 1) | (ge(code) & E);
-    // the level is picked with per-lane all-ones masks, so the step below is straight-line code for the whole wavefront.
-    const unsigned long long s5 = code == 5 ? ~0ull : 0ull, s4 = code == 4 ? ~0ull : 0ull, s3 = code == 3 ? ~0ull : 0ull,
-                             s2 = code == 2 ? ~0ull : 0ull, s1 = code == 1 ? ~0ull : 0ull;
     bool blocked = false;
 #pragma unroll 1
     for (int j = 0; j < ND; j++) { // one row of neighbouring cells per step: the loads of a step are issued together
@@ -1035,65 +1118,118 @@ __device__ __forceinline__ void mask_round_wave(const MaskPtrs &M, const NmsLayo
             dm[k] = dkr[k * 64];
             p0[k] = M.pl0[prow + k]; p1[k] = M.pl1[prow + k]; p2[k] = M.pl2[prow + k];
         }
-        // raster-earlier pixels of those cells (same score level: the earlier one wins)
-        const unsigned long long Eall = dy < 0 ? ~0ull : 0ull, Erow = dy == 0 ? rows_below : 0ull;
         unsigned long long hit = 0ull;
 #pragma unroll
-        for (int k = 0; k < ND; k++) {
-            const int dx = k - RR;
-            const unsigned long long E = Eall | Erow | ((dy == 0 && dx < 0) ? row_mine : 0ull);
-            const unsigned long long ge5 = p2[k] & p0[k], ge4 = p2[k], ge3 = p2[k] | (p1[k] & p0[k]), ge2 = p2[k] | p1[k];
-            const unsigned long long above = (ge5 & s4) | (ge4 & s3) | (ge3 & s2) | (ge2 & s1);
-            const unsigned long long mine = (ge5 & s5) | (ge4 & s4) | (ge3 & s3) | (ge2 & s2) | s1;
-            const unsigned long long needk = ((gm >> k) & 1ull) ? ~0ull : 0ull;
-            hit |= an[k] & dm[k] & (above | (mine & E)) & needk;
-        }
+        for (int k = 0; k < ND; k++)
+            hit |= mask_blockers(m, k - RR, dy, an[k], dm[k], p0[k], p1[k], p2[k]) & (((gm >> k) & 1ull) ? ~0ull : 0ull);
         blocked = blocked || hit != 0ull;
     }
-    const bool accept = live && !blocked;
-    const unsigned long long acc = __ballot(accept);
-    if (!acc) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&M.counters[2], (uint32_t)__popcll(acc));
-    base = (uint32_t)__shfl((int)base, 0);
-    if (accept) {
-        ent_store(M.ent + pc, me | MK_FLAG);
-        atomicAnd(M.alive + pc, 1ull << (uy * 8 + ux)); // any two points of a cell are within r
-#pragma unroll 1
-        for (int j = 0; j < ND; j++) {
-            const uint32_t prow = (uint32_t)(pc + (j - RR) * L.cgw - RR);
-            unsigned long long d[ND];
-#pragma unroll
-            for (int k = 0; k < ND; k++) d[k] = dk[(j * ND + k) * 64];
-#pragma unroll
-            for (int k = 0; k < ND; k++)
-                if (d[k] && !(j == RR && k == RR)) atomicAnd(M.alive + prow + k, ~d[k]);
-        }
-        // the point's raster rank (its index in the raw lists): offset of its 64-pixel row segment + hits before it there
-        const size_t si = (size_t)my * out.ntx + (mx >> 6);
-        const ulonglong2 s01 = *reinterpret_cast<const ulonglong2 *>(out.seg + si * 4);
-        const unsigned long long s2 = out.seg[si * 4 + 2];
-        const uint32_t rank = out.segoff[si] + (uint32_t)__popcll((s01.x | s01.y | s2) & ((1ull << (mx & 63)) - 1ull));
-        const int score = code + 11;
-        M.sortkeys[base + (uint32_t)__popcll(acc & ((1ull << lane) - 1ull))] = sort_key(score, rank);
-        out.raw_xy[rank] = ((uint32_t)my << 16) | (uint32_t)mx;
-        out.raw_score[rank] = score;
-    }
+    mask_accept<RR>(M, L, dk, pc, m, live && !blocked, out);
 }
 
+// Whole-chip round: one 256-lane workgroup per tile of 32 x 8 cells.  The tile and its halo of R cells (alive word,
+// planes, champion entry: 36 bytes per cell) are staged in LDS once, so the 24 or 48 neighbour reads of a lane are LDS
+// reads instead of L1 requests (the per-lane global version was bound by the L1 request rate: 184 us for round 0 of 64
+// frames).  The staged words are a snapshot from the start of the launch: stale alive bits are set bits, which only make
+// a lane wait (safe), and own-cell state is read before anything in this launch can have changed what it means.
+constexpr int MT_W = 32, MT_H = 8;
+
 template <int RR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_nmsm_round(NmsLayout L, int radius, unsigned char *ws_all, size_t ws_stride,
+__global__ __launch_bounds__(256) void k_nmsm_round(NmsLayout L, int radius, unsigned char *ws_all, size_t ws_stride,
                                                     uint32_t *raw_xy_all, int32_t *raw_score_all, int n_cap,
                                                     const unsigned long long *__restrict__ seg_all,
-                                                    const uint32_t *__restrict__ segoff_all, int H, int ntx)
+                                                    const uint32_t *__restrict__ segoff_all, int H, int ntx, int tiles_x)
 {
+    constexpr int ND = 2 * RR + 1, NO = ND * ND, SW = MT_W + 2 * RR, SH = MT_H + 2 * RR, NS = SW * SH;
+    __shared__ unsigned long long s_a[NS], s_p0[NS], s_p1[NS], s_p2[NS];
+    __shared__ uint32_t s_e[NS];
+    __shared__ uint2 s_list[256]; // {staged index, champion key} of the tile's cells under test
+    __shared__ uint32_t s_nlive;
     const int f = blockIdx.y;
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x == 0) s_nlive = 0;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const MaskPtrs M = mask_ptrs(ws_all + (size_t)f * ws_stride, L);
     const size_t nseg = (size_t)H * ntx;
     const MaskOut out{raw_xy_all + (size_t)f * n_cap, raw_score_all + (size_t)f * n_cap, seg_all + (size_t)f * nseg * 4,
                       segoff_all + (size_t)f * nseg, ntx};
-    mask_round_wave<RR>(M, L, reinterpret_cast<const unsigned long long *>(ws_all + L.off_disk), radius, c, c < L.ncell, out);
+    const unsigned long long *disk = reinterpret_cast<const unsigned long long *>(ws_all + L.off_disk);
+    const int cgh = L.gh + 2 * RR;
+    for (int i = threadIdx.x; i < NS; i += 256) { // staged cell (sx, sy) = padded cell (tx * 32 + sx, ty * 8 + sy)
+        const int sy = i / SW, sx = i - sy * SW;
+        const int px = tx * MT_W + sx, py = ty * MT_H + sy;
+        const bool ok = px < L.cgw && py < cgh;
+        const int q = ok ? py * L.cgw + px : 0;
+        const unsigned long long a = ok ? load_alive(M.alive + q) : 0ull;
+        const uint32_t e = ok ? M.ent[q] : 0u;
+        const bool pl = a != 0ull; // closed cells need no planes (most cells after the first rounds)
+        s_a[i] = a;
+        s_e[i] = e;
+        s_p0[i] = pl ? M.pl0[q] : 0ull;
+        s_p1[i] = pl ? M.pl1[q] : 0ull;
+        s_p2[i] = pl ? M.pl2[q] : 0ull;
+    }
+    __syncthreads();
+    // own cells first; the cells that have a champion to test are then packed into a list, so that a tile with a few open
+    // cells costs one wavefront's worth of vector work instead of four (after two rounds most cells are closed)
+    {
+        const int ly = threadIdx.x / MT_W, lx = threadIdx.x - ly * MT_W;
+        const int cx = tx * MT_W + lx, cy = ty * MT_H + ly;
+        const bool incell = cx < L.gw && cy < L.gh;
+        const int si = (ly + RR) * SW + lx + RR;
+        const int pc = (cy + RR) * L.cgw + cx + RR; // lanes outside the frame never use it
+        uint32_t me = s_e[si];
+        const bool live = mask_own(M, pc, cx, cy, incell, me, s_a[si], s_p0[si], s_p1[si], s_p2[si]);
+        const unsigned long long lm = __ballot(live);
+        uint32_t base = 0;
+        if ((threadIdx.x & 63) == 0 && lm) base = atomicAdd(&s_nlive, (uint32_t)__popcll(lm));
+        base = (uint32_t)__shfl((int)base, 0);
+        if (live) {
+            const uint32_t at = base + (uint32_t)__popcll(lm & ((1ull << (threadIdx.x & 63)) - 1ull));
+            s_list[at] = make_uint2((uint32_t)si, me);
+        }
+    }
+    __syncthreads();
+    const int n_live = (int)s_nlive;
+    const int r2 = radius * radius;
+    for (int i0 = (threadIdx.x >> 6) * 64; i0 < n_live; i0 += 256) { // wave-uniform; no barrier below
+        const int i = i0 + (threadIdx.x & 63);
+        const bool live = i < n_live;
+        const uint2 le = live ? s_list[i] : make_uint2((uint32_t)(RR * SW + RR), 0u);
+        const int si = (int)le.x;
+        const int sy = si / SW, sx = si - sy * SW;
+        const int pc = (ty * MT_H + sy) * L.cgw + tx * MT_W + sx;
+        const MaskMe m = mask_me(le.y);
+        const unsigned long long *dk = disk + (m.uy * 8 + m.ux);
+        unsigned long long needm;
+        {
+            uint32_t e[NO];
+#pragma unroll
+            for (int o = 0; o < NO; o++) {
+                const int dx = o % ND - RR, dy = o / ND - RR;
+                e[o] = s_e[si + dy * SW + dx];
+            }
+            needm = live ? mask_need<RR>(m, e, r2) : 0ull;
+        }
+        bool blocked = false;
+#pragma unroll 1
+        for (int j = 0; j < ND; j++) {
+            const int dy = j - RR, g0 = j * ND;
+            const unsigned long long gm = blocked ? 0ull : (needm >> g0) & ((1ull << ND) - 1ull);
+            if (!__any(gm != 0ull)) continue; // nobody in the wavefront needs this row (see mask_round_wave on per-lane skips)
+            const int srow = si + dy * SW - RR;
+            const unsigned long long *dkr = dk + (size_t)g0 * 64;
+            unsigned long long dm[ND];
+#pragma unroll
+            for (int k = 0; k < ND; k++) dm[k] = dkr[k * 64];
+            unsigned long long hit = 0ull;
+#pragma unroll
+            for (int k = 0; k < ND; k++)
+                hit |= mask_blockers(m, k - RR, dy, s_a[srow + k], dm[k], s_p0[srow + k], s_p1[srow + k], s_p2[srow + k]) &
+                       (((gm >> k) & 1ull) ? ~0ull : 0ull);
+            blocked = blocked || hit != 0ull;
+        }
+        mask_accept<RR>(M, L, dk, pc, m, live && !blocked, out);
+    }
 }
 
 __device__ void bitonic_sort_u64(unsigned long long *keys, uint32_t n2p)
@@ -1502,8 +1638,10 @@ void nms_rounds(const NmsLaunch &a, int r0, int n)
     const int ntx = (a.W + 63) / 64;
     for (int r = r0; r < r0 + n; r++) {
         if (L.mask) {
-            if (L.R <= 2) hipLaunchKernelGGL(k_nmsm_round<2>, bgrid, dim3(256), 0, s, L, a.radius, a.ws, a.ws_stride, a.raw_xy, a.raw_score, a.n_cap, a.seg, a.segoff, a.H, ntx);
-            else hipLaunchKernelGGL(k_nmsm_round<3>, bgrid, dim3(256), 0, s, L, a.radius, a.ws, a.ws_stride, a.raw_xy, a.raw_score, a.n_cap, a.seg, a.segoff, a.H, ntx);
+            const int tiles_x = (L.gw + MT_W - 1) / MT_W, tiles_y = (L.gh + MT_H - 1) / MT_H;
+            const dim3 tgrid(tiles_x * tiles_y, a.F);
+            if (L.R <= 2) hipLaunchKernelGGL(k_nmsm_round<2>, tgrid, dim3(256), 0, s, L, a.radius, a.ws, a.ws_stride, a.raw_xy, a.raw_score, a.n_cap, a.seg, a.segoff, a.H, ntx, tiles_x);
+            else hipLaunchKernelGGL(k_nmsm_round<3>, tgrid, dim3(256), 0, s, L, a.radius, a.ws, a.ws_stride, a.raw_xy, a.raw_score, a.n_cap, a.seg, a.segoff, a.H, ntx, tiles_x);
         } else if (L.champ) {
             if (r > 0) hipLaunchKernelGGL(k_nms_champ, bgrid, dim3(256), 0, s, L, a.ws, a.ws_stride);
             if (L.R <= 2) {
@@ -1557,10 +1695,11 @@ NmsLaunch nms_args(hipStream_t s, uint32_t *raw_xy, int32_t *raw_score, const in
     return a;
 }
 
-int wide_rounds_default()
+// mask rounds: 5 measured best on 64 frames of 1080p at r = 16 (2: 0.75 ms, 3: 0.57, 4: 0.50, 5: 0.49, 6: 0.50, 8: 0.52)
+int wide_rounds_default(bool mask = false)
 {
-    static const int v = [] { const char *e = getenv("PGX_NMS_ROUNDS"); int r = e ? atoi(e) : WIDE_ROUNDS; return r < 1 ? 1 : (r > 64 ? 64 : r); }();
-    return v;
+    static const int env = [] { const char *e = getenv("PGX_NMS_ROUNDS"); int r = e ? atoi(e) : 0; return r < 0 ? 0 : (r > 64 ? 64 : r); }();
+    return env ? env : (mask ? 5 : WIDE_ROUNDS);
 }
 
 } // namespace
@@ -1579,7 +1718,7 @@ void pgx_launch_nms(hipStream_t s, uint32_t *raw_xy, int32_t *raw_score, const i
     if (radius >= 0) {
         nms_setup(a);
         // the general path's tail is a plain serial finish: give it fewer leftovers than the champion tail needs
-        used = a.L.champ ? wide_rounds_default() : wide_rounds_default() + 6;
+        used = a.L.mask ? wide_rounds_default(true) : (a.L.champ ? wide_rounds_default() : wide_rounds_default() + 6);
         nms_rounds(a, 0, used);
     }
     nms_finish(a, used);
