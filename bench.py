@@ -510,7 +510,7 @@ def worker(args):
                     "peak": I8_MFMA_PEAK_OPS / 1e12, "unit": "TOP/s", "frac": ops / tt / I8_MFMA_PEAK_OPS,
                     "traffic": traffic.get("ham_argmin"),
                     "algorithmic": "2*P = 512 int8 ops per descriptor-pair evaluation x %d evaluations per step "
-                                   "(device-counted: sum over launches and image pairs of n1*n2; %d wide rounds per chunk of 128 pairs)"
+                                   "(device-counted: sum over launches and image pairs of n1*n2; %d wide rounds per chunk of 256 pairs)"
                                    % (evals, rounds_wide)}
             if "ham_argmin" in kern_alone:
                 ta = kern_alone["ham_argmin"]["ms_per_step"] * 1e-3

@@ -87,6 +87,12 @@ int pgx_set_detect_params(pgx_ctx *ctx, float threshold, int suppression_radius)
  * no cap; default 2^20 = none).  Survivors beyond a call's own `capacity` still raise
  * PGX_E_CAPACITY. */
 int pgx_set_capacity(pgx_ctx *ctx, int max_raw_per_frame, int max_keypoints_per_frame);
+/* Image pairs per workspace chunk of pgx_match_batch_dev / pgx_sequence_step_dev (default 256, [16, 4096]).  A job with
+ * more pairs goes through in chunks whose stages overlap on the device; the chunk bounds the matcher's workspace
+ * (about 4.2 MiB per image pair at 4096 descriptors a side, three chunks resident) and should be large enough that one
+ * chunk's per-pair finish fills the chip (one workgroup per pair: 256 pairs = 256 CUs).  Results do not depend on it.
+ * No reference counterpart (KeypointMatching.cs:14-69 matches one pair per call). */
+int pgx_set_match_chunk(pgx_ctx *ctx, int image_pairs_per_chunk);
 
 /* ---- stage-granular host entry points (one reference function each) ------------------ */
 /* DeWarp.ApplyDistortionMat<Rgba64> (DeWarp.cs:19-37) with the context's map. */

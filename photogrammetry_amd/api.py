@@ -131,6 +131,9 @@ class Engine:
     def set_capacity(self, max_raw_per_frame, max_keypoints_per_frame):
         self._chk(self._L.pgx_set_capacity(self._h, int(max_raw_per_frame), int(max_keypoints_per_frame)))
 
+    def set_match_chunk(self, image_pairs_per_chunk):
+        self._chk(self._L.pgx_set_match_chunk(self._h, int(image_pairs_per_chunk)))
+
     # -- stage-granular host API ----------------------------------------------------------
     def dewarp(self, rgba64):
         a = np.ascontiguousarray(rgba64, dtype=np.uint16)

@@ -121,7 +121,7 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     if (stride <= 0 || stride > (1 << PGX_IDX_BITS)) return fail(c, PGX_E_BADARG, "stride must be in [1, 2^20]");
     if (words <= 0 || words > 127) return fail(c, PGX_E_BADARG, "words must be in [1, 127] (P <= 4064)");
     // image pairs go through in chunks so the per-pair workspace (incl. the tail's 16 MiB distance cache) stays bounded
-    const int CHUNK = 128;
+    const int CHUNK = c->match_chunk;
     const int mc = M < CHUNK ? M : CHUNK;
     HIPCHK(c, c->ws_matchn[0].ensure(pgx_match_ws_bytes(mc, stride)));
     MatchPlan plan;
@@ -351,6 +351,15 @@ int pgx_set_detect_params(pgx_ctx *c, float threshold, int suppression_radius)
     if (!c) return PGX_E_BADARG;
     Lock l(c);
     c->threshold = threshold; c->radius = suppression_radius; c->params_set = true;
+    return PGX_OK;
+}
+
+int pgx_set_match_chunk(pgx_ctx *c, int pairs)
+{
+    if (!c) return PGX_E_BADARG;
+    Lock l(c);
+    if (pairs < 16 || pairs > 4096) return fail(c, PGX_E_BADARG, "image pairs per chunk must be in [16, 4096]");
+    c->match_chunk = pairs;
     return PGX_OK;
 }
 
