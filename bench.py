@@ -704,6 +704,52 @@ def extra_configs(torch, pg, pdist, np, eng, dev, stream, pairs_tbl, dmap):
     finally:
         e4.close()
     torch.cuda.empty_cache()
+    # -- configs[4], one-GPU window variant: 256 x 1920x1080, dewarp -> detect -> match -> RANSAC fundamental -> pose ---------
+    F5, WIN5, NS5, PPS5, THR5 = 256, 16, 2000, 32, 0.001   # samples / pairs per sample / threshold: Program.cs:229 (commented call)
+    with torch.cuda.stream(stream):
+        d_base = torch.from_numpy(base_frame(W, H, 4321)).to(dev)
+        d_frames = roll_frames(torch, d_base, [(3 * i, i) for i in range(F5)])
+        i32 = dict(dtype=torch.int32, device=dev)
+        kp, desc = torch.zeros((F5, NKP, 4), **i32), torch.zeros((F5, NKP, WORDS), **i32)
+        cnt, nraw = torch.zeros(F5, **i32), torch.zeros(F5, **i32)
+        pl_h = [(i, j) for i in range(F5) for j in range(i + 1, min(F5, i + WIN5 + 1))]
+        M5 = len(pl_h)
+        pl = torch.tensor(pl_h, **i32)
+        outp = torch.zeros((M5, NKP, 3), **i32)
+        d_F = torch.zeros((M5, 9), dtype=torch.float32, device=dev)
+        d_in, d_bs = torch.zeros(M5, **i32), torch.zeros(M5, **i32)
+        d_Rt = torch.zeros((M5, 12), dtype=torch.float32, device=dev)
+        d_votes, d_best = torch.zeros((M5, 4), **i32), torch.zeros(M5, **i32)
+
+        def det5():
+            for f0 in range(0, F5, 64):
+                eng.detect_batch_dev(d_frames[f0:f0 + 64], 64, W, H, kp[f0:f0 + 64], desc[f0:f0 + 64], cnt[f0:f0 + 64], nraw[f0:f0 + 64], NKP)
+
+        def mat5():
+            eng.match_batch_dev(desc, cnt, NKP, WORDS, pl, M5, outp, max_count=NKP)
+
+        def ran5():
+            eng.fundamental_ransac_dev(kp, outp, cnt, pl, M5, NKP, NS5, PPS5, THR5, d_F, d_in, d_bs, seed=7)
+
+        def pose5():
+            eng.pose_dev(kp, outp, cnt, pl, M5, NKP, d_F, d_Rt, d_votes, d_best)
+        td, tm, tr, tp = _timed(torch, det5, 1), _timed(torch, mat5, 1), _timed(torch, ran5, 1), _timed(torch, pose5, 1)
+        eng.check_status()
+        c = cnt.cpu().numpy()
+        npairs = float(sum(int(c[a]) * int(c[b]) for a, b in pl_h))
+        inl = d_in.cpu().numpy()
+        votes = d_votes.cpu().numpy()
+        out["config5_pose_window16"] = {
+            "workload": "BASELINE configs[4], one-GPU window variant: 256 x 1920x1080 frames, dewarp -> detect -> match (image pairs "
+                        "0 < j - i <= 16: %d) -> RANSAC fundamental matrix (%d samples x %d pairs, threshold %g: the reference's "
+                        "commented call, Program.cs:229) -> essential matrix / pose with triangulation vote" % (M5, NS5, PPS5, THR5),
+            "detect_s": td, "match_s": tm, "ransac_s": tr, "pose_s": tp, "frames_per_s_end_to_end": F5 / (td + tm + tr + tp),
+            "descriptor_pairs": npairs, "match_pairs_per_s": npairs / tm, "ransac_samples_per_s": M5 * NS5 / tr,
+            "image_pairs_with_a_model": int((inl >= 0).sum()), "inliers_median": float(np.median(inl[inl >= 0])) if (inl >= 0).any() else None,
+            "winning_vote_share_median": float(np.median(votes.max(1) / np.maximum(votes.sum(1), 1))),
+            "note": "pose arithmetic is parity-unpinned (unseeded RNG and MathNet SVD in the reference); timings only"}
+        del d_frames, d_base, kp, desc, cnt, nraw, outp
+    torch.cuda.empty_cache()
     return out
 
 
