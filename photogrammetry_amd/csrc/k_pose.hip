@@ -37,32 +37,43 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t &s)
 template <int N>
 __device__ void jacobi_eig(double (&A)[N][N], double (&V)[N][N])
 {
+#pragma unroll
     for (int i = 0; i < N; i++)
+#pragma unroll
         for (int j = 0; j < N; j++) V[i][j] = i == j ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 40; sweep++) {
         double off = 0.0, diag = 0.0;
+#pragma unroll
         for (int i = 0; i < N; i++) {
             diag += A[i][i] * A[i][i];
+#pragma unroll
             for (int j = i + 1; j < N; j++) off += A[i][j] * A[i][j];
         }
         if (off <= 1e-30 * (diag + 1e-300)) break;
+        // p, q and k unrolled: every index is a compile-time constant, so A and V live in registers (2 x 81 doubles for
+        // N = 9; with run-time indices they sat in scratch and the solver was bound by scratch latency)
+#pragma unroll
         for (int p = 0; p < N - 1; p++)
+#pragma unroll
             for (int q = p + 1; q < N; q++) {
                 const double apq = A[p][q];
                 if (fabs(apq) < 1e-300) continue;
                 const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
                 for (int k = 0; k < N; k++) {
                     const double akp = A[k][p], akq = A[k][q];
                     A[k][p] = c * akp - s * akq;
                     A[k][q] = s * akp + c * akq;
                 }
+#pragma unroll
                 for (int k = 0; k < N; k++) {
                     const double apk = A[p][k], aqk = A[q][k];
                     A[p][k] = c * apk - s * aqk;
                     A[q][k] = s * apk + c * aqk;
                 }
+#pragma unroll
                 for (int k = 0; k < N; k++) {
                     const double vkp = V[k][p], vkq = V[k][q];
                     V[k][p] = c * vkp - s * vkq;
@@ -78,11 +89,24 @@ __device__ void smallest_eigvec(double (&A)[N][N], double (&v)[N])
 {
     double V[N][N];
     jacobi_eig<N>(A, V);
-    int best = 0;
-    for (int i = 1; i < N; i++) if (A[i][i] < A[best][best]) best = i;
-    int big = 0;
-    for (int i = 0; i < N; i++) { v[i] = V[i][best]; if (fabs(v[i]) > fabs(v[big])) big = i; }
-    if (v[big] < 0) for (int i = 0; i < N; i++) v[i] = -v[i];
+    // selections instead of run-time indices (keeps A and V in registers): first smallest diagonal entry, its column
+    double lmin = A[0][0];
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = V[i][0];
+#pragma unroll
+    for (int j = 1; j < N; j++) {
+        const bool take = A[j][j] < lmin;
+        lmin = take ? A[j][j] : lmin;
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] = take ? V[i][j] : v[i];
+    }
+    double vbig = v[0];
+#pragma unroll
+    for (int i = 1; i < N; i++) vbig = fabs(v[i]) > fabs(vbig) ? v[i] : vbig;
+    if (vbig < 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] = -v[i];
+    }
 }
 
 struct PairView {
@@ -107,7 +131,7 @@ __device__ __forceinline__ PairView pair_view(const pgx_keypoint *kp, const pgx_
 // sample record: [0..8] F row-major, [9] inlier count (as float bits of an int)
 constexpr int REC = 10;
 
-__global__ __launch_bounds__(64) void k_fund_samples(const pgx_keypoint *__restrict__ kp, const pgx_pair *__restrict__ matches,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_fund_samples(const pgx_keypoint *__restrict__ kp, const pgx_pair *__restrict__ matches,
                                                      const int32_t *__restrict__ counts, const int32_t *__restrict__ pairlist,
                                                      int stride, int n_samples, int P, float threshold, int rank_check,
                                                      uint64_t seed, float *__restrict__ rec)
@@ -140,15 +164,24 @@ __global__ __launch_bounds__(64) void k_fund_samples(const pgx_keypoint *__restr
     const float t1x = -(float)c1x, t1y = -(float)c1y, t2x = -(float)c2x, t2y = -(float)c2y;
     // A^T A of the P x 9 system (:221-236), rows in float32 like the reference's DenseMatrix
     double G[9][9];
-    for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) G[i][j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) G[i][j] = 0.0;
     for (int k = 0; k < P; k++) {
         const pgx_pair e = pv.ml[idx[k]];
         const float x1 = (float)pv.kpa[e.k1].x + t1x, y1 = (float)pv.kpa[e.k1].y + t1y;
         const float x2 = (float)pv.kpb[e.k2].x + t2x, y2 = (float)pv.kpb[e.k2].y + t2y;
         const float r[9] = {x1 * x2, x1 * y2, x1, y1 * x2, y1 * y2, y1, x2, y2, 1.0f};
-        for (int i = 0; i < 9; i++) for (int j = i; j < 9; j++) G[i][j] += (double)r[i] * (double)r[j];
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+#pragma unroll
+            for (int j = i; j < 9; j++) G[i][j] += (double)r[i] * (double)r[j];
     }
-    for (int i = 0; i < 9; i++) for (int j = 0; j < i; j++) G[i][j] = G[j][i];
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < i; j++) G[i][j] = G[j][i];
     double v[9];
     smallest_eigvec<9>(G, v);
     // F0 = DenseOfColumnMajor(3, 3, lastRow): F0[r][c] = v[3c + r]; F = T2^T * F0 * T1 (:238, :249)
@@ -182,20 +215,48 @@ __global__ __launch_bounds__(64) void k_fund_samples(const pgx_keypoint *__restr
         for (int i = 0; i < 3; i++) rank += sqrt(fmax(B[i][i], 0.0)) > tol ? 1 : 0;
         if (rank != 2) { *outc = -2; return; }
     }
-    // score over ALL keypoint pairs of the list (:53-77), float32
+    *outc = 0; // fitted: k_fund_score counts the inliers
+}
+
+// score of every fitted sample over ALL keypoint pairs of the list (:53-77), float32: one workgroup per (image pair, 256
+// samples); the list's coordinates are gathered once per workgroup into LDS (1024 entries at a time) and every thread
+// walks them as broadcast reads -- per-thread walks through global memory (three dependent loads per entry) took 174 ms
+// for 3960 image pairs x 2000 samples x 4080 entries.
+__global__ __launch_bounds__(256) void k_fund_score(const pgx_keypoint *__restrict__ kp, const pgx_pair *__restrict__ matches,
+                                                    const int32_t *__restrict__ counts, const int32_t *__restrict__ pairlist,
+                                                    int stride, int n_samples, float threshold, float *__restrict__ rec)
+{
+    constexpr int CH = 1024;
+    __shared__ float4 s_xy[CH];
+    const int m = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
+    const PairView pv = pair_view(kp, matches, counts, pairlist, m, stride);
+    const bool active = s < n_samples;
+    float *out = rec + ((size_t)m * n_samples + (active ? s : 0)) * REC;
+    int *outc = reinterpret_cast<int *>(out + 9);
+    const bool fitted = active && *outc == 0;
+    float F[3][3];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) F[r][c] = fitted ? out[3 * r + c] : 0.f;
     int good = 0;
-    for (int e = 0; e < pv.n; e++) {
-        const pgx_pair pr = pv.ml[e];
-        const float x1 = (float)pv.kpa[pr.k1].x, y1 = (float)pv.kpa[pr.k1].y;
-        const float x2 = (float)pv.kpb[pr.k2].x, y2 = (float)pv.kpb[pr.k2].y;
-        // f.Multiply([x2, y2, 1]).DotProduct([x1, y1, 1])
-        const float a0 = F[0][0] * x2 + F[0][1] * y2 + F[0][2];
-        const float a1 = F[1][0] * x2 + F[1][1] * y2 + F[1][2];
-        const float a2 = F[2][0] * x2 + F[2][1] * y2 + F[2][2];
-        const float res = a0 * x1 + a1 * y1 + a2;
-        good += res <= threshold ? 1 : 0;
+    for (int e0 = 0; e0 < pv.n; e0 += CH) { // block-uniform
+        const int cnt = pv.n - e0 < CH ? pv.n - e0 : CH;
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            const pgx_pair pr = pv.ml[e0 + i];
+            s_xy[i] = make_float4((float)pv.kpa[pr.k1].x, (float)pv.kpa[pr.k1].y, (float)pv.kpb[pr.k2].x, (float)pv.kpb[pr.k2].y);
+        }
+        __syncthreads();
+        for (int i = 0; i < cnt; i++) {
+            const float4 q = s_xy[i];
+            const float x1 = q.x, y1 = q.y, x2 = q.z, y2 = q.w;
+            // f.Multiply([x2, y2, 1]).DotProduct([x1, y1, 1])
+            const float a0 = F[0][0] * x2 + F[0][1] * y2 + F[0][2];
+            const float a1 = F[1][0] * x2 + F[1][1] * y2 + F[1][2];
+            const float a2 = F[2][0] * x2 + F[2][1] * y2 + F[2][2];
+            const float res = a0 * x1 + a1 * y1 + a2;
+            good += res <= threshold ? 1 : 0;
+        }
     }
-    *outc = good;
+    if (fitted) *outc = good;
 }
 
 // first sample with the largest count (`workingPairs.Count > bestSample.Count`, :79-84)
@@ -396,6 +457,8 @@ void pgx_launch_fundamental(hipStream_t s, const pgx_keypoint *kp, const pgx_pai
     float *rec = reinterpret_cast<float *>(ws);
     hipLaunchKernelGGL(k_fund_samples, dim3((n_samples + 63) / 64, M), dim3(64), 0, s, kp, matches, counts, pairlist, stride,
                        n_samples, P, threshold, rank_check, seed, rec);
+    hipLaunchKernelGGL(k_fund_score, dim3((n_samples + 255) / 256, M), dim3(256), 0, s, kp, matches, counts, pairlist, stride, n_samples,
+                       threshold, rec);
     hipLaunchKernelGGL(k_fund_pick, dim3(M), dim3(256), 0, s, rec, n_samples, F_out, inliers, best_sample);
 }
 
