@@ -24,7 +24,7 @@ frames and pairs of all sequences dealt round-robin over the ranks, so both exch
 
 Extra objects on the JSON line:
   roofline      the dominant kernel of the step by measured time (HIP events on the launch stream, timed steps)
-  mfma          the metric's kernel (k_ham_mfma): achieved int8 op/s against the dense int8 MFMA peak
+  mfma          the metric's kernel (k_ham_fp4): achieved multiply-add op/s against the dense FP4 MFMA peak (10 PF)
   rooflines / kernels   every kernel group; traffic = HBM bytes from separate rocprofv3 --pmc passes (profiles/)
   match_only    pairs/s of the match stage alone (SURVEY 8d's definition of the metric)
   configs       (N = 1) the other BASELINE configurations on this GPU: configs[1] x 64 independent pairs,
@@ -50,7 +50,11 @@ NKP = 4096
 RADIUS = 16
 THRESH = 0.1
 SEQ_FRAMES = 64
-I8_MFMA_PEAK_OPS = 5.0e15   # dense int8 MFMA, /opt/skills/guides/MI355X_MICROARCH.md (2x the 2.5 PF bf16 figure)
+# The distance kernel runs on the block-scaled FP4 matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4, e2m1 operands
+# +-1, exact): its dense peak is the FP6/FP4 figure of /opt/skills/guides/MI355X_MICROARCH.md (4x the 2.5 PF bf16 rate).
+# PGX_HAM_FP4=0 selects the int8 kernel of the first half of round 2, whose pipe peaks at 5.0e15.
+MFMA_FP4 = os.environ.get("PGX_HAM_FP4", "4") != "0"
+I8_MFMA_PEAK_OPS = 10.0e15 if MFMA_FP4 else 5.0e15   # name kept: operations of the 256-bit +-1 contraction per second
 HBM_PEAK = 8.0e12
 TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
@@ -509,7 +513,9 @@ def worker(args):
             mfma = {"kernel": "ham_argmin", "bound": "mfma", "achieved": ops / tt / 1e12,
                     "peak": I8_MFMA_PEAK_OPS / 1e12, "unit": "TOP/s", "frac": ops / tt / I8_MFMA_PEAK_OPS,
                     "traffic": traffic.get("ham_argmin"),
-                    "algorithmic": "2*P = 512 int8 ops per descriptor-pair evaluation x %d evaluations per step "
+                    "matrix_dtype": "fp4 e2m1 (+-1, exact), f32 accumulate, block scale 2^13" if MFMA_FP4 else "int8 (+-64), i32 accumulate",
+                    "frac_of_int8_peak": ops / tt / 5.0e15,
+                    "algorithmic": "2*P = 512 ops per descriptor-pair evaluation x %d evaluations per step "
                                    "(device-counted: sum over launches and image pairs of n1*n2; %d wide rounds per chunk of 256 pairs)"
                                    % (evals, rounds_wide)}
             if "ham_argmin" in kern_alone:
@@ -531,7 +537,8 @@ def worker(args):
             "metric": "descriptor pairs matched/sec", "value": pairs_per_step * args.steps / dt_max,
             "unit": "descriptor pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "u8 (descriptor bits expanded to int8 for the MFMA distance; integer keys); f32 grey",
+            "dtype": "u8 / bits (descriptor bits expanded to fp4 +-1 for the MFMA distance: exact integers in f32 accumulators; "
+                     "integer keys); f32 grey",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] (SURVEY 8d config 3) x %d: %d-frame 1920x1080 RGBA64 sequence(s), "
                                    "dewarp(%s)+gray+FAST(T=0.1)+NMS(r=%d)+BRIEF-256 per frame, all %d ordered image pairs per sequence "
