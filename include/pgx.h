@@ -209,6 +209,10 @@ int  pgx_tracks_get(pgx_tracks *t, int32_t *track_offsets /* [n_tracks + 1] */, 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------- */
 /* When on, the named hot kernels are bracketed by HIP events on the launch stream. */
 int pgx_profile_enable(pgx_ctx *ctx, int on);
+/* Bracket only the kernel group `name` (NULL or "": every group again).  Two event records per launch cost about 10 us
+ * of device time each way on a busy stream (0.6 ms per step of the bench job with every launch bracketed): the timed
+ * region of bench.py brackets the dominant kernel only, the untimed stand-alone pass brackets everything. */
+int pgx_profile_filter(pgx_ctx *ctx, const char *name);
 /* Sums since the last reset for kernel `name` ("dewarp_gray", "fast", "ham_argmin", ...):
  * launches and total milliseconds.  Synchronises the stream. */
 int pgx_profile_get(pgx_ctx *ctx, const char *name, int *launches, double *total_ms);

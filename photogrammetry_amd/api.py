@@ -249,6 +249,9 @@ class Engine:
     def profile_enable(self, on=True):
         self._chk(self._L.pgx_profile_enable(self._h, 1 if on else 0))
 
+    def profile_filter(self, name=None):
+        self._chk(self._L.pgx_profile_filter(self._h, name.encode() if name else None))
+
     def profile_serialize(self, on=True):
         self._chk(self._L.pgx_profile_serialize(self._h, 1 if on else 0))
 

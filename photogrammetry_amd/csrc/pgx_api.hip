@@ -622,6 +622,14 @@ int pgx_profile_enable(pgx_ctx *c, int on)
     return PGX_OK;
 }
 
+int pgx_profile_filter(pgx_ctx *c, const char *name)
+{
+    if (!c) return PGX_E_BADARG;
+    Lock l(c);
+    c->prof_only = name ? name : "";
+    return PGX_OK;
+}
+
 static void prof_drain(pgx_ctx *c)
 {
     for (auto &kv : c->prof) {

@@ -97,6 +97,7 @@ struct pgx_ctx {
 
     // profiling
     bool prof_on = false;
+    std::string prof_only; // when not empty: only this kernel group is bracketed (pgx_profile_filter)
     bool prof_serial = false; // matcher stages in order on one stream (stand-alone kernel times)
     std::map<std::string, ProfEntry> prof;
     std::vector<hipEvent_t> ev_pool; // recycled timing events (creating two per launch costs more than the record itself)
@@ -134,7 +135,7 @@ struct ProfScope {
     hipStream_t st;
     ProfScope(pgx_ctx *ctx, const char *name, hipStream_t s = nullptr) : c(ctx), st(s ? s : ctx->stream)
     {
-        if (!c->prof_on) return;
+        if (!c->prof_on || (!c->prof_only.empty() && c->prof_only != name)) return;
         e = &c->prof[name];
         auto take = [&](hipEvent_t &ev) {
             if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); return true; }
