@@ -53,7 +53,7 @@ SEQ_FRAMES = 64
 # The distance kernel runs on the block-scaled FP4 matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4, e2m1 operands
 # +-1, exact): its dense peak is the FP6/FP4 figure of /opt/skills/guides/MI355X_MICROARCH.md (4x the 2.5 PF bf16 rate).
 # PGX_HAM_FP4=0 selects the int8 kernel of the first half of round 2, whose pipe peaks at 5.0e15.
-MFMA_FP4 = os.environ.get("PGX_HAM_FP4", "3") != "0"
+MFMA_FP4 = os.environ.get("PGX_HAM_FP4", "2") != "0"
 I8_MFMA_PEAK_OPS = 10.0e15 if MFMA_FP4 else 5.0e15   # name kept: operations of the 256-bit +-1 contraction per second
 HBM_PEAK = 8.0e12
 TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")

@@ -650,7 +650,8 @@ void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc
     if (plan.words == 8) {
         const size_t n2p = pow2_ge((size_t)(plan.max_n > 1 ? plan.max_n : 1));
         const size_t key_cap = n2p <= 8192 ? n2p : 0; // sort keys in LDS up to 32 KiB, else in the workspace
-        hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(GS_NT), key_cap * 4, s, ws, d_desc, d_pairlist, plan.stride, d_out,
+        static const int gs_nt = [] { const char *e = getenv("PGX_GS_NT"); int v = e ? atoi(e) : GS_NT; return (v == 256 || v == 512 || v == 1024) ? v : GS_NT; }(); // developer A/B switch
+        hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(gs_nt), key_cap * 4, s, ws, d_desc, d_pairlist, plan.stride, d_out,
                            (uint32_t)key_cap, status);
     } else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out, status);
 }
