@@ -77,6 +77,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-dewarp", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs / host_api objects (N = 1)")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
+    ap.add_argument("--no-overlap-exchange", action="store_true",
+                    help="N > 1: run the all-gather of the match lists synchronously at the end of every step (default: it is issued "
+                         "asynchronously and awaited one step later, double-buffered; the last one is awaited inside the timed region)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="jobs kept in flight: consecutive steps alternate between this many contexts (each with its own streams and "
                          "buffers), so one job's detect / exchanges run beside another job's match (measured on one GPU: 12.61 ms per step "
@@ -350,7 +353,8 @@ def worker(args):
             e.set_match_chunk(int(os.environ["PGX_BENCH_CHUNK"]))
         e.set_dewarp_map(dmap)
         engs.append(e)
-        jobs.append(pdist.ShardedSequence(e, W, H, n_frames, pair_list, NKP, WORDS, dev, stream=torch.cuda.Stream(device=dev)))
+        jobs.append(pdist.ShardedSequence(e, W, H, n_frames, pair_list, NKP, WORDS, dev, stream=torch.cuda.Stream(device=dev),
+                                          overlap_exchange=not args.no_overlap_exchange))
     eng, job = engs[0], jobs[0]
     stream = job.stream
     step_no = [0]
@@ -381,6 +385,8 @@ def worker(args):
 
     for _ in range(max(NI, args.warmup)):
         run_step()
+    for j in jobs:
+        j.finish()
     torch.cuda.synchronize()
     for e in engs:
         e.check_status()
@@ -405,6 +411,8 @@ def worker(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_step()
+    for j in jobs:
+        j.finish()   # the last steps' match-list exchanges belong to the timed region
     barrier()
     dt = time.perf_counter() - t0
     dbg = [0] * 8
@@ -424,6 +432,7 @@ def worker(args):
         eng.profile_enable(True)
         for _ in range(k_alone):
             job.step(d_frames)
+        job.finish()
         torch.cuda.synchronize()
         eng.profile_enable(False)
         eng.profile_serialize(False)

@@ -176,12 +176,19 @@ class ShardedSequence:
     `step()` only enqueues (pgx kernels and the collectives share `stream`).  Frames are addressed in
     the gathered buffers through slot_of(); the pair list handed to the matcher is pre-mapped."""
 
-    def __init__(self, engine, W, H, n_frames, pair_list, nkp, words, device, stream=None, group=None, comm="torch"):
+    def __init__(self, engine, W, H, n_frames, pair_list, nkp, words, device, stream=None, group=None, comm="torch",
+                 overlap_exchange=False):
         """comm = "torch": the two exchanges are torch.distributed all_gather_into_tensor calls (RCCL under the "nccl"
         backend, gloo in the CPU tests); comm = "pgx": the whole step is ONE C-ABI call, pgx_sequence_step_dev, on the
-        context's own RCCL communicator (engine.comm_init must have run; what a non-Python host would use)."""
+        context's own RCCL communicator (engine.comm_init must have run; what a non-Python host would use).
+        overlap_exchange (torch path, G > 1): the all-gather of the match lists -- by far the larger exchange, 12 B x nkp
+        per image pair -- is issued asynchronously into one of TWO output buffers and awaited one step later, so it runs
+        beside the next step's detect and match instead of after this step's; `finish()` awaits the last one and must be
+        called before the lists are read.  `out_all` / `matches()` then refer to the step issued last."""
         assert comm in ("torch", "pgx")
         self.comm = comm
+        self.overlap = bool(overlap_exchange) and comm == "torch"
+        self._pending = None
         self.e, self.W, self.H, self.nkp, self.words = engine, W, H, nkp, words
         self.rank, self.world = _world()
         self.group = group
@@ -197,7 +204,9 @@ class ShardedSequence:
         i32 = dict(dtype=torch.int32, device=device)
         self.desc_all = torch.zeros((G * self.fs, nkp, words), **i32)
         self.counts_all = torch.zeros(G * self.fs, **i32)
-        self.out_all = torch.zeros((G * self.ps, nkp, 3), **i32)
+        self.out_bufs = [torch.zeros((G * self.ps, nkp, 3), **i32) for _ in range(2 if (self.overlap and G > 1) else 1)]
+        self._cur = 0
+        self.out_all = self.out_bufs[0]
         self.kp_l = torch.zeros((self.fs, nkp, 4), **i32)
         self.nraw_l = torch.zeros(self.fs, **i32)
         lo_f, lo_p = self.rank * self.fs, self.rank * self.ps
@@ -224,11 +233,31 @@ class ShardedSequence:
             if self.world > 1:
                 dist.all_gather_into_tensor(self.desc_all, self.desc_l, group=self.group)
                 dist.all_gather_into_tensor(self.counts_all, self.counts_l, group=self.group)
+            out_all = self.out_bufs[self._cur]
+            lo_p = self.rank * self.ps
+            out_l = out_all[lo_p:lo_p + self.ps]
             if npr:
                 self.e.match_batch_dev(self.desc_all, self.counts_all, self.nkp, self.words, self.pairlist_l, npr,
-                                       self.out_l, max_count=self.nkp)
+                                       out_l, max_count=self.nkp)
+            self.out_all, self.out_l = out_all, out_l
             if self.world > 1:
-                dist.all_gather_into_tensor(self.out_all, self.out_l, group=self.group)
+                if self.overlap:
+                    # the gather issued one step ago filled the OTHER buffer; it has had this whole step to complete, and
+                    # the next step's matcher writes into that buffer, so the stream waits for it here
+                    if self._pending is not None:
+                        self._pending.wait()
+                    self._pending = dist.all_gather_into_tensor(out_all, out_l, group=self.group, async_op=True)
+                    self._cur ^= 1
+                else:
+                    dist.all_gather_into_tensor(out_all, out_l, group=self.group)
+
+    def finish(self):
+        """Await the match-list exchange of the last step (overlap_exchange); a no-op otherwise."""
+        import contextlib
+        if self._pending is not None:
+            with (torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()):
+                self._pending.wait()
+            self._pending = None
 
     # -- views for consumers (host side) ---------------------------------------------------------
     def counts(self):

@@ -175,7 +175,7 @@ class _OracleEngine:
             out[m] = torch.from_numpy(_match(d[a], int(c[a]), d[b], int(c[b])))
 
 
-def _seq_worker(rank, world, port, q):
+def _seq_worker(rank, world, port, q, overlap=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -183,10 +183,13 @@ def _seq_worker(rank, world, port, q):
         pairs = cref.gaussian_pairs(0, 20, 256)
         fr = _frames()
         pl = pdist.all_pairs(N_FRAMES)
-        job = pdist.ShardedSequence(_OracleEngine(pairs), W, H, N_FRAMES, pl, CAP, 8, "cpu")
+        job = pdist.ShardedSequence(_OracleEngine(pairs), W, H, N_FRAMES, pl, CAP, 8, "cpu", overlap_exchange=overlap)
         mine = torch.from_numpy(np.stack([fr[f] for f in job.my_frames]))
         job.step(mine)
         job.step(mine)   # a second step over the same buffers must give the same answer
+        if overlap:
+            job.step(mine)   # three steps: both output buffers have been gathered into and reused
+        job.finish()
         desc = np.stack([job.descriptors(f).numpy() for f in range(N_FRAMES)])
         out = np.stack([job.matches(p).numpy() for p in range(len(pl))])
         q.put((rank, desc, job.counts(), out))
@@ -195,13 +198,14 @@ def _seq_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_sequence_equals_single_process(world):
-    """5 frames / 10 image pairs over 2 and 3 ranks (uneven shares: padding slots on the last ranks)."""
+@pytest.mark.parametrize("world,overlap", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_sequence_equals_single_process(world, overlap):
+    """5 frames / 10 image pairs over 2 and 3 ranks (uneven shares: padding slots on the last ranks); with and without the
+    overlapped (asynchronous, double-buffered) exchange of the match lists."""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_seq_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_seq_worker, args=(r, world, port, q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(world)]
