@@ -66,6 +66,12 @@ int  pgx_set_stream(pgx_ctx *ctx, void *hip_stream);
 int  pgx_check_status(pgx_ctx *ctx);
 
 /* ---- init-time configuration (replaces DI-bound options, Program.cs:61-69) ----------- */
+/* Pixel type of every `rgba` argument below (host and device): PGX_SRC_RGBA64 (default) = 4 x uint16 as
+ * Rgba64 (Rgba64.cs:3-9); PGX_SRC_RGBA8 = 4 x uint8, widened on the device to c * 257 per channel, which is what an
+ * 8-bit file becomes when LocalImageReader loads it as Rgba64 (LocalImageReader.cs:22; SURVEY 8f-4 "ingest"): half the
+ * upload and half the gathered bytes, identical results.  pgx_dewarp's output stays Rgba64. */
+enum { PGX_SRC_RGBA64 = 0, PGX_SRC_RGBA8 = 1 };
+int pgx_set_source_format(pgx_ctx *ctx, int format);
 /* DeWarpTransformStepFactory.Initialize (DeWarpTransformStepFactory.cs:26-31): the Matrix<Uv>
  * built by DeWarp.GetDistortionMatrix, as host int32 [H][W][2] = (U, V).  NULL = stage off. */
 int pgx_set_dewarp_map(pgx_ctx *ctx, const int32_t *uv, int W, int H);

@@ -28,6 +28,7 @@ internal static unsafe class PgxNative
     [DllImport(Lib)] public static extern int pgx_set_brief_pairs(IntPtr ctx, int* pairs, int p);
     [DllImport(Lib)] public static extern int pgx_set_detect_params(IntPtr ctx, float threshold, int suppressionRadius);
     [DllImport(Lib)] public static extern int pgx_set_capacity(IntPtr ctx, int maxRaw, int maxKeypoints);
+    [DllImport(Lib)] public static extern int pgx_set_source_format(IntPtr ctx, int format); // 0 = Rgba64, 1 = Rgba32 bytes (widened x257 on the device)
     [DllImport(Lib)] public static extern int pgx_set_match_chunk(IntPtr ctx, int imagePairsPerChunk);
     [DllImport(Lib)] public static extern int pgx_dewarp(IntPtr ctx, ushort* rgba64, int w, int h, ushort* outRgba64);
     [DllImport(Lib)] public static extern int pgx_gray(IntPtr ctx, ushort* rgba64, int w, int h, float* outGray);

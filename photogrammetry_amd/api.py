@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (PGX_DIST_NONE, PGX_E_BADARG, PGX_E_CAPACITY, PGX_E_DIM_MISMATCH, PGX_E_EMPTY_SET,
+from ._lib import (PGX_DIST_NONE, PGX_SRC_RGBA64, PGX_SRC_RGBA8, PGX_E_BADARG, PGX_E_CAPACITY, PGX_E_DIM_MISMATCH, PGX_E_EMPTY_SET,
                    PGX_E_HIP, PGX_E_NOT_CONFIGURED, PGX_E_OOB_SOURCE, PGX_OK)
 
 KEYPOINT_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("fast_score", "<i4"), ("value", "<f4")])
@@ -131,18 +131,23 @@ class Engine:
     def set_capacity(self, max_raw_per_frame, max_keypoints_per_frame):
         self._chk(self._L.pgx_set_capacity(self._h, int(max_raw_per_frame), int(max_keypoints_per_frame)))
 
+    def set_source_format(self, fmt):
+        """PGX_SRC_RGBA64 (0, default) or PGX_SRC_RGBA8 (1): 8-bit frames, widened x257 on the device (pgx.h)."""
+        self._chk(self._L.pgx_set_source_format(self._h, int(fmt)))
+        self._src_dtype = np.uint8 if int(fmt) == PGX_SRC_RGBA8 else np.uint16
+
     def set_match_chunk(self, image_pairs_per_chunk):
         self._chk(self._L.pgx_set_match_chunk(self._h, int(image_pairs_per_chunk)))
 
     # -- stage-granular host API ----------------------------------------------------------
     def dewarp(self, rgba64):
-        a = np.ascontiguousarray(rgba64, dtype=np.uint16)
-        out = np.empty_like(a)
+        a = np.ascontiguousarray(rgba64, dtype=getattr(self, "_src_dtype", np.uint16))
+        out = np.empty(a.shape, dtype=np.uint16)
         self._chk(self._L.pgx_dewarp(self._h, _ptr(a), a.shape[1], a.shape[0], _ptr(out)))
         return out
 
     def gray(self, rgba64):
-        a = np.ascontiguousarray(rgba64, dtype=np.uint16)
+        a = np.ascontiguousarray(rgba64, dtype=getattr(self, "_src_dtype", np.uint16))
         out = np.empty(a.shape[:2], dtype=np.float32)
         self._chk(self._L.pgx_gray(self._h, _ptr(a), a.shape[1], a.shape[0], _ptr(out)))
         return out
@@ -178,7 +183,7 @@ class Engine:
         return out[:len(d1)].copy()
 
     def detect(self, rgba64, capacity=8192):
-        a = np.ascontiguousarray(rgba64, dtype=np.uint16)
+        a = np.ascontiguousarray(rgba64, dtype=getattr(self, "_src_dtype", np.uint16))
         kp = np.zeros(capacity, dtype=KEYPOINT_DTYPE)
         desc = np.zeros((capacity, max(1, self.words)), dtype=np.uint32)
         n, nraw = C.c_int(0), C.c_int(0)

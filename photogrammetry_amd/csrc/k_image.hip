@@ -2,7 +2,7 @@
 //
 // Reference: ImageProcessing/DeWarp.cs:19-37 (integer gather through the Matrix<Uv> table) and
 // Images.Abstractions/Pixels/Grayscale.cs:19-23 (K = ((float)R + B + G) / (3*65535), float32).
-// HBM-bound: per pixel and frame 8 B gathered source + 4 B grey, plus 8 B of map per pixel and group of
+// HBM-bound: per pixel and frame 8 B gathered source (4 B for 8-bit sources, widened in registers) + 4 B grey, plus 8 B of map per pixel and group of
 // FB = 4 frames (the map is the same for every frame of a batch): 14 B/px/frame; FAST re-reads the 4 B.
 // Layout: every thread owns 4 consecutive output pixels of FB frames -> two 16-B map loads, then per
 // frame four 8-B gathers and one 16-B grey store.
@@ -21,17 +21,31 @@ __device__ __forceinline__ float gray_of(uint2 px)
 
 constexpr int FB = 4; // frames per thread: one map read serves FB frames
 
-template <bool HAS_MAP, bool WRITE_RGBA>
-__global__ __launch_bounds__(256) void k_dewarp_gray(const uint2 *__restrict__ rgba, const int2 *__restrict__ map,
-                                                     int W, int H, int F, float *__restrict__ gray,
-                                                     uint2 *__restrict__ dewarped, int *status)
+// 8-bit sources (PGX_SRC_RGBA8): a channel c becomes c * 257 = c | c << 8, the scaling an 8-bit image gets when it is
+// loaded as Rgba64 (LocalImageReader.cs:22 via ImageSharp; 255 -> 65535).  Bytes r,g,b,a -> words r,r,g,g | b,b,a,a.
+__device__ __forceinline__ uint2 widen8(uint32_t v)
 {
+    return make_uint2(__builtin_amdgcn_perm(v, v, 0x01010000u), __builtin_amdgcn_perm(v, v, 0x03030202u));
+}
+
+template <bool SRC8> struct SrcPix { using type = uint2; };
+template <> struct SrcPix<true> { using type = uint32_t; };
+template <bool SRC8> __device__ __forceinline__ uint2 load_px(const typename SrcPix<SRC8>::type *p);
+template <> __device__ __forceinline__ uint2 load_px<false>(const uint2 *p) { return *p; }
+template <> __device__ __forceinline__ uint2 load_px<true>(const uint32_t *p) { return widen8(*p); }
+
+template <bool HAS_MAP, bool WRITE_RGBA, bool SRC8>
+__global__ __launch_bounds__(256) void k_dewarp_gray(const typename SrcPix<SRC8>::type *__restrict__ rgba,
+                                                     const int2 *__restrict__ map, int W, int H, int F,
+                                                     float *__restrict__ gray, uint2 *__restrict__ dewarped, int *status)
+{
+    using Px = typename SrcPix<SRC8>::type;
     const size_t npix = (size_t)W * H;
     const int f0 = blockIdx.y * FB;
     const int nf = F - f0 < FB ? F - f0 : FB; // block-uniform
     const size_t ngroups = (npix + 3) / 4;
     // 16-byte accesses at frame f's base need f * npix to be a multiple of 4 pixels: odd frame sizes in a batch
-    // take the scalar path (block-uniform)
+    // take the scalar path (block-uniform; the same for 4-byte source pixels, where 4 pixels are one 16-byte load)
     const bool vec = (npix & 3) == 0 || F == 1;
     bool oob = false;
     for (size_t grp = (size_t)blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups;
@@ -58,10 +72,13 @@ __global__ __launch_bounds__(256) void k_dewarp_gray(const uint2 *__restrict__ r
 #pragma unroll
             for (int fb = 0; fb < FB; fb++) {
                 if (fb >= nf) break;
-                const uint2 *src = rgba + (size_t)(f0 + fb) * npix;
+                const Px *src = rgba + (size_t)(f0 + fb) * npix;
                 if (HAS_MAP) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) px[fb][k] = src[so[k]];
+                    for (int k = 0; k < 4; k++) px[fb][k] = load_px<SRC8>(src + so[k]);
+                } else if constexpr (SRC8) {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(src + i0);
+                    px[fb][0] = widen8(a.x); px[fb][1] = widen8(a.y); px[fb][2] = widen8(a.z); px[fb][3] = widen8(a.w);
                 } else {
                     const uint4 a = *reinterpret_cast<const uint4 *>(src + i0);
                     const uint4 b = *reinterpret_cast<const uint4 *>(src + i0 + 2);
@@ -98,7 +115,7 @@ __global__ __launch_bounds__(256) void k_dewarp_gray(const uint2 *__restrict__ r
                     o = okk ? (size_t)sv * W + su : 0;
                 }
                 for (int fb = 0; fb < nf; fb++) {
-                    const uint2 p = okk ? rgba[(size_t)(f0 + fb) * npix + o] : make_uint2(0, 0);
+                    const uint2 p = okk ? load_px<SRC8>(rgba + (size_t)(f0 + fb) * npix + o) : make_uint2(0, 0);
                     if (gray) gray[(size_t)(f0 + fb) * npix + i] = gray_of(p);
                     if (WRITE_RGBA) dewarped[(size_t)(f0 + fb) * npix + i] = p;
                 }
@@ -180,7 +197,7 @@ __global__ __launch_bounds__(256) void k_dewarp_map(int W, int H, double k0, dou
 
 } // namespace
 
-void pgx_launch_dewarp_gray(hipStream_t s, const uint16_t *rgba, const int32_t *map_uv, int F, int W, int H,
+void pgx_launch_dewarp_gray(hipStream_t s, const void *rgba, int src8, const int32_t *map_uv, int F, int W, int H,
                             float *gray, uint16_t *dewarped, int *status)
 {
     if (F <= 0 || W <= 0 || H <= 0) return;
@@ -188,16 +205,18 @@ void pgx_launch_dewarp_gray(hipStream_t s, const uint16_t *rgba, const int32_t *
     unsigned gx = (unsigned)((ngroups + 255) / 256);
     if (gx > 4096u) gx = 4096u; // >> 256 CUs, grid-stride beyond
     dim3 grid(gx, (unsigned)((F + FB - 1) / FB)), block(256);
-    const uint2 *src = reinterpret_cast<const uint2 *>(rgba);
     const int2 *map = reinterpret_cast<const int2 *>(map_uv);
     uint2 *dw = reinterpret_cast<uint2 *>(dewarped);
-    if (map) {
-        if (dw) hipLaunchKernelGGL((k_dewarp_gray<true, true>), grid, block, 0, s, src, map, W, H, F, gray, dw, status);
-        else hipLaunchKernelGGL((k_dewarp_gray<true, false>), grid, block, 0, s, src, map, W, H, F, gray, dw, status);
+#define PGX_DG(M, WR, S8) hipLaunchKernelGGL((k_dewarp_gray<M, WR, S8>), grid, block, 0, s, \
+                                             reinterpret_cast<const SrcPix<S8>::type *>(rgba), map, W, H, F, gray, dw, status)
+    if (src8) {
+        if (map) { if (dw) PGX_DG(true, true, true); else PGX_DG(true, false, true); }
+        else { if (dw) PGX_DG(false, true, true); else PGX_DG(false, false, true); }
     } else {
-        if (dw) hipLaunchKernelGGL((k_dewarp_gray<false, true>), grid, block, 0, s, src, map, W, H, F, gray, dw, status);
-        else hipLaunchKernelGGL((k_dewarp_gray<false, false>), grid, block, 0, s, src, map, W, H, F, gray, dw, status);
+        if (map) { if (dw) PGX_DG(true, true, false); else PGX_DG(true, false, false); }
+        else { if (dw) PGX_DG(false, true, false); else PGX_DG(false, false, false); }
     }
+#undef PGX_DG
 }
 
 void pgx_launch_dewarp_map(hipStream_t s, int W, int H, const double *k, int32_t *map_uv, int *status)

@@ -88,7 +88,7 @@ int enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_
     float *gray = c->ws_gray.as<float>();
     {
         ProfScope ps(c, "dewarp_gray");
-        pgx_launch_dewarp_gray(c->stream, d_rgba, c->map_set ? c->d_map.as<int32_t>() : nullptr, F, W, H, gray,
+        pgx_launch_dewarp_gray(c->stream, d_rgba, c->src8, c->map_set ? c->d_map.as<int32_t>() : nullptr, F, W, H, gray,
                                nullptr, c->d_status);
     }
     {
@@ -363,6 +363,15 @@ int pgx_set_match_chunk(pgx_ctx *c, int pairs)
     return PGX_OK;
 }
 
+int pgx_set_source_format(pgx_ctx *c, int format)
+{
+    if (!c) return PGX_E_BADARG;
+    Lock l(c);
+    if (format != PGX_SRC_RGBA64 && format != PGX_SRC_RGBA8) return fail(c, PGX_E_BADARG, "unknown source format %d", format);
+    c->src8 = format == PGX_SRC_RGBA8;
+    return PGX_OK;
+}
+
 int pgx_set_capacity(pgx_ctx *c, int max_raw, int max_kp)
 {
     if (!c) return PGX_E_BADARG;
@@ -381,11 +390,11 @@ int pgx_dewarp(pgx_ctx *c, const uint16_t *rgba, int W, int H, uint16_t *out)
     if (!c->map_set) return fail(c, PGX_E_NOT_CONFIGURED, "pgx_set_dewarp_map not called");
     if (W != c->mapW || H != c->mapH)   // DeWarp.cs:22-23
         return fail(c, PGX_E_DIM_MISMATCH, "image %dx%d vs dewarp map %dx%d (ArgumentException)", W, H, c->mapW, c->mapH);
-    const size_t bytes = (size_t)W * H * 8;
+    const size_t bytes = (size_t)W * H * 8, in_bytes = (size_t)W * H * (c->src8 ? 4 : 8);
     HIPCHK(c, c->st_a.ensure(bytes + 32));
     HIPCHK(c, c->st_b.ensure(bytes + 32));
-    HIPCHK(c, hipMemcpyAsync(c->st_a.p, rgba, bytes, hipMemcpyHostToDevice, c->stream));
-    pgx_launch_dewarp_gray(c->stream, c->st_a.as<uint16_t>(), c->d_map.as<int32_t>(), 1, W, H, nullptr,
+    HIPCHK(c, hipMemcpyAsync(c->st_a.p, rgba, in_bytes, hipMemcpyHostToDevice, c->stream));
+    pgx_launch_dewarp_gray(c->stream, c->st_a.p, c->src8, c->d_map.as<int32_t>(), 1, W, H, nullptr,
                            c->st_b.as<uint16_t>(), c->d_status);
     HIPCHK(c, hipMemcpyAsync(out, c->st_b.p, bytes, hipMemcpyDeviceToHost, c->stream));
     return sync_status(c);
@@ -399,8 +408,8 @@ int pgx_gray(pgx_ctx *c, const uint16_t *rgba, int W, int H, float *out)
     const size_t npix = (size_t)W * H;
     HIPCHK(c, c->st_a.ensure(npix * 8 + 32));
     HIPCHK(c, c->st_b.ensure(npix * 4 + 32));
-    HIPCHK(c, hipMemcpyAsync(c->st_a.p, rgba, npix * 8, hipMemcpyHostToDevice, c->stream));
-    pgx_launch_dewarp_gray(c->stream, c->st_a.as<uint16_t>(), nullptr, 1, W, H, c->st_b.as<float>(), nullptr,
+    HIPCHK(c, hipMemcpyAsync(c->st_a.p, rgba, npix * (c->src8 ? 4 : 8), hipMemcpyHostToDevice, c->stream));
+    pgx_launch_dewarp_gray(c->stream, c->st_a.p, c->src8, nullptr, 1, W, H, c->st_b.as<float>(), nullptr,
                            c->d_status);
     HIPCHK(c, hipMemcpyAsync(out, c->st_b.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
     return sync_status(c);
@@ -543,7 +552,7 @@ int pgx_detect(pgx_ctx *c, const uint16_t *rgba, int W, int H, pgx_keypoint *kp_
     pgx_keypoint *d_kp = c->st_f.as<pgx_keypoint>();
     uint32_t *d_desc = reinterpret_cast<uint32_t *>(d_kp + capacity);
     int32_t *d_cnt = reinterpret_cast<int32_t *>(d_desc + (size_t)capacity * (c->words ? c->words : 1));
-    HIPCHK(c, hipMemcpyAsync(c->st_e.p, rgba, npix * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->st_e.p, rgba, npix * (c->src8 ? 4 : 8), hipMemcpyHostToDevice, c->stream));
     int rc = enqueue_detect(c, c->st_e.as<uint16_t>(), 1, W, H, d_kp, d_desc, d_cnt, d_cnt + 1, capacity);
     if (rc != PGX_OK) return rc;
     int cnt[2] = {0, 0};

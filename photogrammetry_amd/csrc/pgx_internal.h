@@ -75,6 +75,7 @@ struct pgx_ctx {
     // image pairs per matcher workspace chunk (pgx_set_match_chunk).  128 left three quarters of the chip idle during a
     // chunk's per-pair finish (one workgroup per pair, two per CU): stand-alone finish 6.2 ms per 2016 pairs; 256: 3.7 ms
     int match_chunk = 256;
+    int src8 = 0; // pgx_set_source_format: 1 = the rgba arguments are 8-bit RGBA
 
     // status words: [0] sticky error bits
     int *d_status = nullptr;
@@ -157,7 +158,8 @@ struct ProfScope {
 // ---------------------------------------------------------------------------------------
 
 // k_image.hip
-void pgx_launch_dewarp_gray(hipStream_t s, const uint16_t *rgba, const int32_t *map_uv, int F, int W, int H,
+// rgba: [F][H][W] pixels of 4 x uint16 (src8 = 0) or 4 x uint8 (src8 = 1, widened x257 in registers)
+void pgx_launch_dewarp_gray(hipStream_t s, const void *rgba, int src8, const int32_t *map_uv, int F, int W, int H,
                             float *gray, uint16_t *dewarped, int *status);
 void pgx_launch_dewarp_map(hipStream_t s, int W, int H, const double *k /*[5]*/, int32_t *map_uv, int *status);
 
