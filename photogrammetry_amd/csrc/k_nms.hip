@@ -1036,9 +1036,12 @@ __device__ __forceinline__ unsigned long long mask_blockers(const MaskMe &m, int
 
 // accept the champions of the lanes with `accept`: stamp, suppress everything within r, emit the output records.
 // Called by whole wavefronts.
+// `snap` (optional): alive words staged earlier in this launch, snap[k + j * snap_w] = the cell at offset (k - RR, j - RR)
+// from the accepting cell.  Bits only ever clear, so a staged word is a superset of the current one and a neighbour whose
+// staged word has nothing inside the disk needs no atomic at all (two of three neighbouring cells on the bench frames).
 template <int RR>
 __device__ __forceinline__ void mask_accept(const MaskPtrs &M, const NmsLayout &L, const unsigned long long *dk, int pc, const MaskMe &m,
-                                            bool accept, const MaskOut &out)
+                                            bool accept, const MaskOut &out, const unsigned long long *snap = nullptr, int snap_w = 0)
 {
     constexpr int ND = 2 * RR + 1;
     const int lane = threadIdx.x & 63;
@@ -1056,6 +1059,10 @@ __device__ __forceinline__ void mask_accept(const MaskPtrs &M, const NmsLayout &
             unsigned long long d[ND];
 #pragma unroll
             for (int k = 0; k < ND; k++) d[k] = dk[(j * ND + k) * 64];
+            if (snap) {
+#pragma unroll
+                for (int k = 0; k < ND; k++) d[k] &= snap[j * snap_w + k];
+            }
 #pragma unroll
             for (int k = 0; k < ND; k++)
                 if (d[k] && !(j == RR && k == RR)) atomicAnd(M.alive + prow + k, ~d[k]);
@@ -1228,7 +1235,7 @@ __global__ __launch_bounds__(256) void k_nmsm_round(NmsLayout L, int radius, uns
                        (((gm >> k) & 1ull) ? ~0ull : 0ull);
             blocked = blocked || hit != 0ull;
         }
-        mask_accept<RR>(M, L, dk, pc, m, live && !blocked, out);
+        mask_accept<RR>(M, L, dk, pc, m, live && !blocked, out, s_a + si - RR * SW - RR, SW);
     }
 }
 
