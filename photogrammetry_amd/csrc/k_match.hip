@@ -628,7 +628,9 @@ void pgx_launch_match_rows(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, 
     uint32_t *ws = reinterpret_cast<uint32_t *>(wsv);
     ProfScope ps(ctx, "tail_rows", s);
     if (pgx_mfma_enabled()) { // the matrix-pipe version (k_match_mfma.inc); PGX_DISABLE_MFMA=1 selects the xor+popcount one
-        hipLaunchKernelGGL(k_tail_rows_mfma, dim3(PGX_TAIL_MAX / TM_ROWS, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
+        static const bool rows_fp4 = [] { const char *e = getenv("PGX_ROWS_FP4"); return !(e && e[0] == '0'); }(); // developer A/B switch
+        if (rows_fp4) hipLaunchKernelGGL(k_tail_rows_fp4, dim3(PGX_TAIL_MAX / TM_ROWS, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
+        else hipLaunchKernelGGL(k_tail_rows_mfma, dim3(PGX_TAIL_MAX / TM_ROWS, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
         return;
     }
     static bool attr_set = false;
