@@ -10,8 +10,10 @@
 set -e
 cd "$(dirname "$0")/../.."
 C=photogrammetry_amd/csrc
+BASE=348b354   # the commit whose k_nms.hip the patch was cut against (the forms under test do not depend on later changes)
 cp $C/k_nms.hip /tmp/k_nms_ship.hip
 trap 'cp /tmp/k_nms_ship.hip '$C'/k_nms.hip' EXIT
+git show $BASE:$C/k_nms.hip > $C/k_nms.hip
 patch -p1 < tests/nmsexp/experiment.patch
 OBJS="pgx_api.o pgx_comm.o k_image.o k_fast.o k_brief.o k_match.o k_pose.o pgx_hostutil.o pgx_tracks.o"
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Iinclude"
