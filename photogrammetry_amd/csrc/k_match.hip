@@ -265,19 +265,58 @@ __global__ __launch_bounds__(SEL_NT) void k_match_select(uint32_t *ws, int S, un
     select_compact_wg(p, parity, wsum);
 }
 
-// bitonic sort of `n2p` (power of two) u32 keys, ascending, by the whole workgroup
+// bitonic sort of `n2p` (power of two) u32 keys, ascending, by the whole workgroup.  The sort is bound by LDS traffic
+// (one read and one write of every key per stage, 78 stages for 4096 keys: timed inside k_match_gs at 39 us with 512
+// threads), so up to three consecutive stages j = 4s, 2s, s of a merge are fused: a thread takes the 8 keys whose indices
+// differ in the bits s, 2s, 4s, runs the three compare-exchange layers in registers and writes them back -- 30 passes
+// over the keys instead of 78.  The direction bit k lies above all three, so the 8 keys of a thread share it.
 __device__ void bitonic_sort_wg(uint32_t *keys, uint32_t n2p)
 {
     const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    auto cx = [](uint32_t &a, uint32_t &b, bool up) {
+        const uint32_t mn = a < b ? a : b, mx = a < b ? b : a;
+        a = up ? mn : mx;
+        b = up ? mx : mn;
+    };
     for (uint32_t k = 2; k <= n2p; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        uint32_t j = k >> 1;
+        while (j > 0) {
             __syncthreads();
-            for (uint32_t t = tid; t < n2p / 2; t += nth) {
-                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t hi = lo | j;
-                const bool up = (lo & k) == 0;
-                const uint32_t a = keys[lo], b = keys[hi];
-                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            if (j >= 4) { // stages j, j/2, j/4 together; s = j/4
+                const uint32_t s4 = j >> 2;
+                for (uint32_t t = tid; t < n2p / 8; t += nth) {
+                    // spread t around three zero bits at s, 2s, 4s
+                    const uint32_t base = ((t & ~(s4 - 1)) << 3) | (t & (s4 - 1));
+                    const bool up = (base & k) == 0;
+                    uint32_t v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) v[q] = keys[base + (uint32_t)q * s4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) cx(v[q], v[q + 4], up);                       // partner distance 4s = j
+#pragma unroll
+                    for (int q = 0; q < 8; q++) if ((q & 2) == 0) cx(v[q], v[q + 2], up);    // 2s
+#pragma unroll
+                    for (int q = 0; q < 8; q += 2) cx(v[q], v[q + 1], up);                   // s
+#pragma unroll
+                    for (int q = 0; q < 8; q++) keys[base + (uint32_t)q * s4] = v[q];
+                }
+                j >>= 3;
+            } else { // the last one or two stages of a merge (j = 2, 1 or j = 1), or k <= 4
+                const uint32_t jj = j; // stages jj .. 1 on 2 * jj consecutive keys per group
+                for (uint32_t t = tid; t < n2p / (2 * jj); t += nth) {
+                    const uint32_t base = t * 2 * jj;
+                    const bool up = (base & k) == 0;
+                    if (jj == 2) {
+                        uint32_t v0 = keys[base], v1 = keys[base + 1], v2 = keys[base + 2], v3 = keys[base + 3];
+                        cx(v0, v2, up); cx(v1, v3, up); cx(v0, v1, up); cx(v2, v3, up);
+                        keys[base] = v0; keys[base + 1] = v1; keys[base + 2] = v2; keys[base + 3] = v3;
+                    } else {
+                        uint32_t v0 = keys[base], v1 = keys[base + 1];
+                        cx(v0, v1, up);
+                        keys[base] = v0; keys[base + 1] = v1;
+                    }
+                }
+                j = 0;
             }
         }
     }
