@@ -597,6 +597,16 @@ __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uin
 
 } // namespace
 
+// The residual byte matrix of an image pair (k_tail_rows* write it, k_match_gs reads it): rows start on 128-byte lines.
+// The rows kernel is bound by its HBM writes, and a store instruction of it covers 16 rows x 64 bytes: with rows on line
+// boundaries the two halves of a line come from neighbouring wavefronts of one workgroup and leave L2 as whole lines
+// (tools/probe/write_pattern.hip: 120 -> 96 us for 385 MB in that pattern).
+__device__ __forceinline__ int tail_row_stride(int C) { return (C + 127) & ~127; }
+__device__ __forceinline__ uint8_t *tail_matrix(const PairWs &p)
+{
+    return reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(p.dcache) + 127) & ~(uintptr_t)127);
+}
+
 #include "k_match_tail.inc"
 #include "k_match_mfma.inc"
 
