@@ -654,13 +654,11 @@ void pgx_launch_match_wide(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, 
         hipLaunchKernelGGL(k_match_init, dim3((plan.stride + 255) / 256 > 64 ? 64 : (plan.stride + 255) / 256, plan.M),
                            dim3(256), 0, s, ws, d_counts, d_pairlist, plan.stride, plan.max_n, status);
     }
-    const bool mfma_ok = (plan.words == 8) && pgx_mfma_enabled();
     for (int r = 0; r < plan.rounds_mfma; r++) {
         {
             ProfScope ps(ctx, "ham_argmin", s);
-            if (mfma_ok) pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan);
-            else if (plan.words == 8) launch_rounds_valu<8>(s, ws, d_desc, d_pairlist, plan);
-            else launch_rounds_valu<0>(s, ws, d_desc, d_pairlist, plan);
+            if (plan.words == 8) pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan);   // 256-bit descriptors: the matrix pipe
+            else launch_rounds_valu<0>(s, ws, d_desc, d_pairlist, plan);                // any other length: xor + popcount
         }
         {
             ProfScope ps(ctx, "match_select", s);
@@ -676,20 +674,7 @@ void pgx_launch_match_rows(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, 
     if (plan.M <= 0 || plan.words != 8) return;
     uint32_t *ws = reinterpret_cast<uint32_t *>(wsv);
     ProfScope ps(ctx, "tail_rows", s);
-    if (pgx_mfma_enabled()) { // the matrix-pipe version (k_match_mfma.inc); PGX_DISABLE_MFMA=1 selects the xor+popcount one
-        static const bool rows_fp4 = [] { const char *e = getenv("PGX_ROWS_FP4"); return !(e && e[0] == '0'); }(); // developer A/B switch
-        if (rows_fp4) hipLaunchKernelGGL(k_tail_rows_fp4, dim3(PGX_TAIL_MAX / TM_ROWS, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
-        else hipLaunchKernelGGL(k_tail_rows_mfma, dim3(PGX_TAIL_MAX / TM_ROWS, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
-        return;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)tail_rows_lds_bytes());
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_tail_rows, dim3(PGX_TAIL_MAX / TF_ROWS, plan.M), dim3(TF_NT), tail_rows_lds_bytes(), s, ws, d_desc,
-                       d_pairlist, plan.stride);
+    hipLaunchKernelGGL(k_tail_rows_fp4, dim3(PGX_TAIL_MAX / TM_ROWS, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
 }
 
 void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_pairlist,
@@ -701,8 +686,7 @@ void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc
     if (plan.words == 8) {
         const size_t n2p = pow2_ge((size_t)(plan.max_n > 1 ? plan.max_n : 1));
         const size_t key_cap = n2p <= 8192 ? n2p : 0; // sort keys in LDS up to 32 KiB, else in the workspace
-        static const int gs_nt = [] { const char *e = getenv("PGX_GS_NT"); int v = e ? atoi(e) : GS_NT; return (v == 256 || v == 512 || v == 1024) ? v : GS_NT; }(); // developer A/B switch
-        hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(gs_nt), key_cap * 4, s, ws, d_desc, d_pairlist, plan.stride, d_out,
+        hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(GS_NT), key_cap * 4, s, ws, d_desc, d_pairlist, plan.stride, d_out,
                            (uint32_t)key_cap, status);
     } else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out, status);
 }

@@ -56,12 +56,12 @@ __host__ __device__ inline int nms_champ_cs(int radius, int n_cap, bool planes)
 }
 
 // mask rounds: 8-pixel cells (r = 10..21) on frames whose coordinates fit 14 bits each (position-ordered 32-bit keys)
-__host__ __device__ inline bool nms_mask_ok(int W, int H, int radius, int n_cap, bool planes, bool allow)
+__host__ __device__ inline bool nms_mask_ok(int W, int H, int radius, int n_cap, bool planes)
 {
-    return allow && nms_champ_cs(radius, n_cap, planes) == 8 && W <= 16384 && H <= 16384;
+    return nms_champ_cs(radius, n_cap, planes) == 8 && W <= 16384 && H <= 16384;
 }
 
-__host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_cap, bool planes, bool allow_mask = true)
+__host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_cap, bool planes)
 {
     NmsLayout L;
     const int ccs = nms_champ_cs(radius, n_cap, planes);
@@ -74,7 +74,7 @@ __host__ __device__ inline NmsLayout nms_layout(int W, int H, int radius, int n_
     L.gh = (H + cs - 1) / cs; if (L.gh < 1) L.gh = 1;
     L.ncell = L.gw * L.gh;
     L.cgw = L.gw + 2 * L.R;
-    L.mask = nms_mask_ok(W, H, radius, n_cap, planes, allow_mask) ? 1 : 0;
+    L.mask = nms_mask_ok(W, H, radius, n_cap, planes) ? 1 : 0;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     if (L.mask) { // per padded cell: alive word, three score planes, champion key; per frame: open-cell lists, the accepted points' keys
@@ -1588,13 +1588,7 @@ __global__ __launch_bounds__(NT) void k_nmsm_tail(const int32_t *raw_score_all, 
 
 } // namespace
 
-static bool mask_allowed() // developer A/B switch: PGX_NMS_MASK=0 sends 8-pixel cells through the record-based champion rounds
-{
-    static const bool v = [] { const char *e = getenv("PGX_NMS_MASK"); return !(e && e[0] == '0'); }();
-    return v;
-}
-
-size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap, bool planes) { return nms_layout(W, H, radius, n_cap, planes, mask_allowed()).total; }
+size_t pgx_nms_ws_bytes(int W, int H, int radius, int n_cap, bool planes) { return nms_layout(W, H, radius, n_cap, planes).total; }
 
 bool pgx_nms_fills_raw_lists(int W, int H, int radius, int n_cap) { return radius >= 0 && nms_layout(W, H, radius, n_cap, true).champ != 0; }
 
@@ -1697,7 +1691,7 @@ NmsLaunch nms_args(hipStream_t s, uint32_t *raw_xy, int32_t *raw_score, const in
     a.radius = radius; a.ws = reinterpret_cast<unsigned char *>(wsv); a.ws_stride = ws_stride; a.order = order;
     a.n_kept = n_kept; a.kp_cap = kp_cap; a.status = status; a.seg = seg; a.segoff = segoff;
     const bool have_planes = seg && segoff;
-    a.L = nms_layout(W, H, radius, n_cap, have_planes, mask_allowed());
+    a.L = nms_layout(W, H, radius, n_cap, have_planes);
     a.planes = have_planes && (a.L.cs == 8 || a.L.cs == 16 || a.L.cs == 32 || a.L.cs == 64);
     return a;
 }
@@ -1705,8 +1699,7 @@ NmsLaunch nms_args(hipStream_t s, uint32_t *raw_xy, int32_t *raw_score, const in
 // mask rounds: 5 measured best on 64 frames of 1080p at r = 16 (2: 0.75 ms, 3: 0.57, 4: 0.50, 5: 0.49, 6: 0.50, 8: 0.52)
 int wide_rounds_default(bool mask = false)
 {
-    static const int env = [] { const char *e = getenv("PGX_NMS_ROUNDS"); int r = e ? atoi(e) : 0; return r < 0 ? 0 : (r > 64 ? 64 : r); }();
-    return env ? env : (mask ? 5 : WIDE_ROUNDS);
+    return mask ? 5 : WIDE_ROUNDS;
 }
 
 } // namespace

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                                                      int stride, int n_samples, int P, float threshold, int rank_check,
                                                      uint64_t seed, float *__restrict__ rec)
 {
-    const int m = blockIdx.y, s = blockIdx.x * 64 + threadIdx.x;
+    const int m = blockIdx.x, s = blockIdx.y * 64 + threadIdx.x;   // image pairs in grid.x: any number of them (grid.y holds 65535 at most)
     if (s >= n_samples) return;
     const PairView pv = pair_view(kp, matches, counts, pairlist, m, stride);
     float *out = rec + ((size_t)m * n_samples + s) * REC;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_fund_score(const pgx_keypoint *__restri
 {
     constexpr int CH = 1024;
     __shared__ float4 s_xy[CH];
-    const int m = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.x, s = blockIdx.y * 256 + threadIdx.x;
     const PairView pv = pair_view(kp, matches, counts, pairlist, m, stride);
     const bool active = s < n_samples;
     float *out = rec + ((size_t)m * n_samples + (active ? s : 0)) * REC;
@@ -455,9 +455,9 @@ void pgx_launch_fundamental(hipStream_t s, const pgx_keypoint *kp, const pgx_pai
 {
     if (M <= 0 || n_samples <= 0) return;
     float *rec = reinterpret_cast<float *>(ws);
-    hipLaunchKernelGGL(k_fund_samples, dim3((n_samples + 63) / 64, M), dim3(64), 0, s, kp, matches, counts, pairlist, stride,
+    hipLaunchKernelGGL(k_fund_samples, dim3(M, (n_samples + 63) / 64), dim3(64), 0, s, kp, matches, counts, pairlist, stride,
                        n_samples, P, threshold, rank_check, seed, rec);
-    hipLaunchKernelGGL(k_fund_score, dim3((n_samples + 255) / 256, M), dim3(256), 0, s, kp, matches, counts, pairlist, stride, n_samples,
+    hipLaunchKernelGGL(k_fund_score, dim3(M, (n_samples + 255) / 256), dim3(256), 0, s, kp, matches, counts, pairlist, stride, n_samples,
                        threshold, rec);
     hipLaunchKernelGGL(k_fund_pick, dim3(M), dim3(256), 0, s, rec, n_samples, F_out, inliers, best_sample);
 }

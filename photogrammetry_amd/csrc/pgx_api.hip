@@ -59,12 +59,13 @@ int sync_status(pgx_ctx *c)
     return decode_status(c, c->h_status[0]);
 }
 
-// detect chain on device-resident frames (enqueue only)
-int enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_keypoint *d_kp, uint32_t *d_desc,
-                   int32_t *d_counts, int32_t *d_nraw, int cap)
+// every check and workspace allocation of the detect chain (no kernel launch): pgx_sequence_step_dev calls it before its
+// first collective so that no rank can fail locally between two collectives
+int prepare_detect(pgx_ctx *c, int F, int W, int H, int cap)
 {
     if (!c->params_set) return fail(c, PGX_E_NOT_CONFIGURED, "pgx_set_detect_params not called");
     if (!c->pairs_set) return fail(c, PGX_E_NOT_CONFIGURED, "pgx_set_brief_pairs not called");
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return fail(c, PGX_E_BADARG, "dimensions must fit ushort");
     if (c->map_set && (c->mapW != W || c->mapH != H))
         return fail(c, PGX_E_DIM_MISMATCH, "image %dx%d vs dewarp map %dx%d (ArgumentException)", W, H, c->mapW, c->mapH);
     if (F <= 0) return PGX_OK;
@@ -78,12 +79,25 @@ int enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_
     HIPCHK(c, c->ws_rawscore.ensure((size_t)F * raw_cap * 4));
     const size_t nms_stride = pgx_nms_ws_bytes(W, H, c->radius, raw_cap, true);
     HIPCHK(c, c->ws_nms.ensure((size_t)F * nms_stride));
+    const int kp_eff = c->kp_cap <= cap ? c->kp_cap : cap;
+    HIPCHK(c, c->ws_order.ensure((size_t)F * kp_eff * 4));
+    HIPCHK(c, c->ws_nkept.ensure((size_t)F * 4));
+    return PGX_OK;
+}
+
+// detect chain on device-resident frames (enqueue only)
+int enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_keypoint *d_kp, uint32_t *d_desc,
+                   int32_t *d_counts, int32_t *d_nraw, int cap)
+{
+    const int rcp = prepare_detect(c, F, W, H, cap);
+    if (rcp != PGX_OK) return rcp;
+    if (F <= 0) return PGX_OK;
+    const int raw_cap = c->raw_cap;
+    const size_t nms_stride = pgx_nms_ws_bytes(W, H, c->radius, raw_cap, true);
     // pgx_set_capacity's survivor limit: lists are cut to their first kp_cap entries (NMS order) without an error;
     // only an overflow of the caller's own `cap` raises PGX_E_CAPACITY
     const bool kp_soft = c->kp_cap <= cap;
     const int kp_eff = kp_soft ? c->kp_cap : cap;
-    HIPCHK(c, c->ws_order.ensure((size_t)F * kp_eff * 4));
-    HIPCHK(c, c->ws_nkept.ensure((size_t)F * 4));
 
     float *gray = c->ws_gray.as<float>();
     {
@@ -114,16 +128,27 @@ int enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_
     return PGX_OK;
 }
 
-int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, int stride, int words,
-                  const int32_t *d_pairlist, int M, int max_n, pgx_pair *d_out)
+// checks and workspace allocation of the matcher for M image pairs of `stride` descriptor slots (no kernel launch)
+int prepare_match(pgx_ctx *c, int stride, int words, int M)
 {
     if (M <= 0) return PGX_OK;
     if (stride <= 0 || stride > (1 << PGX_IDX_BITS)) return fail(c, PGX_E_BADARG, "stride must be in [1, 2^20]");
     if (words <= 0 || words > 127) return fail(c, PGX_E_BADARG, "words must be in [1, 127] (P <= 4064)");
-    // image pairs go through in chunks so the per-pair workspace (incl. the tail's 16 MiB distance cache) stays bounded
     const int CHUNK = c->match_chunk;
     const int mc = M < CHUNK ? M : CHUNK;
-    HIPCHK(c, c->ws_matchn[0].ensure(pgx_match_ws_bytes(mc, stride)));
+    const int nws = (M <= CHUNK || c->prof_serial) ? 1 : 3;
+    for (int k = 0; k < nws; k++) HIPCHK(c, c->ws_matchn[k].ensure(pgx_match_ws_bytes(mc, stride)));
+    return PGX_OK;
+}
+
+int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, int stride, int words,
+                  const int32_t *d_pairlist, int M, int max_n, pgx_pair *d_out)
+{
+    if (M <= 0) return PGX_OK;
+    const int rcp = prepare_match(c, stride, words, M);
+    if (rcp != PGX_OK) return rcp;
+    // image pairs go through in chunks so the per-pair workspace stays bounded
+    const int CHUNK = c->match_chunk;
     MatchPlan plan;
     plan.stride = stride; plan.words = words;
     plan.max_n = max_n > stride ? stride : (max_n < 1 ? 1 : max_n);
@@ -133,15 +158,10 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     // 256-bit descriptors: k_tail_rows caches the residual's distance rows up to PGX_TAIL_MAX, so wide rounds stop there;
     // other lengths: the tail workgroup stages the descriptors itself (PGX_TAIL_FILL_MAX)
     plan.skip_below = words == 8 ? PGX_TAIL_MAX : PGX_TAIL_FILL_MAX;
-    {
-        static const int ovr = [] { const char *e = getenv("PGX_SKIP_BELOW"); return e ? atoi(e) : 0; }(); // developer A/B switch
-        if (ovr > 0 && ovr <= PGX_TAIL_MAX && words == 8) plan.skip_below = ovr;
-    }
     for (int n = plan.max_n; n > plan.skip_below && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
     if (plan.rounds_mfma > 0 && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS) plan.rounds_mfma++;
     HIPCHK(c, hipMemsetAsync(c->d_status + 4, 0, PGX_MAX_WIDE_ROUNDS * 8, c->stream));
-    static const bool overlap = [] { const char *e = getenv("PGX_MATCH_OVERLAP"); return !(e && e[0] == '0'); }(); // developer A/B switch
-    if (M <= CHUNK || !overlap || c->prof_serial) { // everything in order on the context's stream
+    if (M <= CHUNK || c->prof_serial) { // everything in order on the context's stream
         for (int m0 = 0; m0 < M; m0 += CHUNK) {
             plan.M = (M - m0 < CHUNK) ? M - m0 : CHUNK;
             const int32_t *pl = d_pairlist + 2 * (size_t)m0;
@@ -162,7 +182,6 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
         int lo = 0, hi = 0;
         HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi)); // lo = least priority (numerically greatest)
         for (int k = 0; k < NS; k++) {
-            HIPCHK(c, c->ws_matchn[k].ensure(pgx_match_ws_bytes(mc, stride)));
             if (!c->mstream[k]) {
                 const int prio = k == 0 ? lo : (k == 2 ? hi : (lo + hi) / 2);
                 HIPCHK(c, hipStreamCreateWithPriority(&c->mstream[k], hipStreamNonBlocking, prio));
@@ -216,6 +235,8 @@ int pgx_enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_count
 {
     return enqueue_match(c, d_desc, d_counts, stride, words, d_pairlist, M, max_n, d_out);
 }
+int pgx_prepare_detect(pgx_ctx *c, int F, int W, int H, int cap) { return prepare_detect(c, F, W, H, cap); }
+int pgx_prepare_match(pgx_ctx *c, int stride, int words, int M) { return prepare_match(c, stride, words, M); }
 
 extern "C" {
 
@@ -600,7 +621,8 @@ int pgx_fundamental_ransac_dev(pgx_ctx *c, const pgx_keypoint *d_kp, const pgx_p
     Lock l(c);
     if (pairs_per_sample < 8) // CameraPoseEstimation.cs:28-29
         return fail(c, PGX_E_BADARG, "At least 8 keypoint pairs must be included per sample (InvalidOperationException)");
-    if (pairs_per_sample > 64 || n_samples <= 0) return fail(c, PGX_E_BADARG, "pairs_per_sample must be <= 64 and n_samples > 0");
+    if (pairs_per_sample > 64 || n_samples <= 0 || n_samples > 65535 * 64)
+        return fail(c, PGX_E_BADARG, "pairs_per_sample must be <= 64 and n_samples in [1, 4194240]");
     if (M == 0) return PGX_OK;
     HIPCHK(c, c->ws_pose.ensure(pgx_pose_ws_bytes(M, n_samples)));
     pgx_launch_fundamental(c->stream, d_kp, d_matches, d_counts, d_pairlist, M, stride, n_samples, pairs_per_sample, threshold,

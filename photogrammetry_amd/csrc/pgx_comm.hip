@@ -4,12 +4,21 @@
 // fixed-size records (per-frame {count, descriptors}; per-image-pair match lists: the reference always emits exactly N1
 // entries, KeypointMatching.cs:38), so the ABI offers an in-place all-gather on the context's stream and the four-phase
 // step built from it.  RCCL is loaded at run time (dlopen) so that libpgx.so itself has no link-time dependency: a
-// single-GPU host never touches it, and a missing library surfaces as PGX_E_RCCL from pgx_comm_init, nowhere else.
+// single-GPU host never touches it, and a missing library surfaces as PGX_E_RCCL from pgx_comm_unique_id / pgx_comm_init,
+// nowhere else.  PGX_RCCL_LIB names the library file to load instead of the default search (deployment knob: a host that
+// ships its own RCCL build; the CPU test of the missing-library path points it at a file that does not exist).
+//
+// Failure on ONE rank: a collective is a rendezvous, so a rank that returned early would leave its peers waiting in the
+// all-gather for ever.  pgx_sequence_step_dev therefore does every rank-local check and every workspace allocation BEFORE
+// the first collective, and if a local call still fails after that point it aborts the communicator (ncclCommAbort): the
+// peers' pending collectives then fail with PGX_E_RCCL instead of hanging, and this context is left without a communicator.
+// N > 1 on RCCL has only ever run under the driver's multi-GPU bench (the development box has one GPU).
 #include "pgx_internal.h"
 
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -25,6 +34,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr; // optional
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
@@ -36,15 +46,22 @@ Rccl *rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        const char *only = getenv("PGX_RCCL_LIB");
+        std::string why;
         for (const char *n : names) {
+            if (only && only[0]) n = only;
             r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (r.h) break;
+            const char *e = dlerror();   // ONE call: dlerror() clears the message it returns
+            if (why.empty()) why = e ? e : "?";
+            if (only && only[0]) break;
         }
-        if (!r.h) { r.err = std::string("dlopen(librccl.so.1) failed: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!r.h) { r.err = "dlopen(librccl) failed: " + why; return; }
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.h, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.h, "ncclCommInitRank"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.h, "ncclCommDestroy"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.h, "ncclAllGather"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.h, "ncclCommAbort"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.h, "ncclGetErrorString"));
         if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) r.err = "librccl lacks an expected nccl* symbol";
     });
@@ -66,6 +83,8 @@ int pgx_enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, 
                        int32_t *d_counts, int32_t *d_nraw, int cap);
 int pgx_enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, int stride, int words,
                       const int32_t *d_pairlist, int M, int max_n, pgx_pair *d_out);
+int pgx_prepare_detect(pgx_ctx *c, int F, int W, int H, int cap);
+int pgx_prepare_match(pgx_ctx *c, int stride, int words, int M);
 
 extern "C" {
 
@@ -76,6 +95,7 @@ int pgx_comm_unique_id(void *id_out)
     if (!r->err.empty()) return PGX_E_RCCL;
     ncclUniqueId id;
     if (r->GetUniqueId(&id) != ncclSuccessV) return PGX_E_RCCL;
+    static_assert(sizeof id == PGX_COMM_ID_BYTES, "pgx.h promises the size of ncclUniqueId");
     memcpy(id_out, &id, sizeof id);
     return PGX_OK;
 }
@@ -150,21 +170,37 @@ int pgx_sequence_step_dev(pgx_ctx *c, const uint16_t *d_frames_local, int n_loca
     std::lock_guard<std::mutex> g(c->mu);
     (void)hipSetDevice(c->device);
     if (!c->pairs_set) { c->err = "pgx_set_brief_pairs not called"; return PGX_E_NOT_CONFIGURED; }
+    if (c->comm_world > 1 && !c->comm) { c->err = "pgx_comm_init not called"; return PGX_E_NOT_CONFIGURED; }
     const int words = c->words, r = c->comm_rank;
+    // every rank-local check and allocation first: nothing below this block fails for a local reason in normal operation
+    int rc = pgx_prepare_detect(c, n_local_frames, W, H, capacity);
+    if (rc == PGX_OK) rc = pgx_prepare_match(c, capacity, words, n_local_pairs);
+    if (rc != PGX_OK) return rc;   // before any collective: the peers see this rank's error through the host, not a hang
+    // from here on a local failure aborts the communicator so that the peers' collectives fail instead of waiting
+    auto bail = [&](int code) {
+        if (c->comm_world > 1 && c->comm) {
+            Rccl *q = rccl();
+            if (q->CommAbort) (void)q->CommAbort(reinterpret_cast<ncclComm_t>(c->comm));
+            c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+            c->err += " (communicator aborted: the other ranks' collectives fail with PGX_E_RCCL)";
+        }
+        return code;
+    };
     // phase 1: detect the frames this rank owns, straight into its block of the gathered buffers
     uint32_t *desc_l = d_desc_all + (size_t)r * frame_slots * capacity * words;
     int32_t *counts_l = d_counts_all + (size_t)r * frame_slots;
-    int rc = pgx_enqueue_detect(c, d_frames_local, n_local_frames, W, H, d_kp_local, desc_l, counts_l, d_nraw_local, capacity);
-    if (rc != PGX_OK) return rc;
+    rc = pgx_enqueue_detect(c, d_frames_local, n_local_frames, W, H, d_kp_local, desc_l, counts_l, d_nraw_local, capacity);
+    if (rc != PGX_OK) return bail(rc);
     // phase 2: the fixed-size per-frame records
-    if ((rc = allgather_locked(c, d_desc_all, (size_t)frame_slots * capacity * words * 4)) != PGX_OK) return rc;
-    if ((rc = allgather_locked(c, d_counts_all, (size_t)frame_slots * 4)) != PGX_OK) return rc;
+    if ((rc = allgather_locked(c, d_desc_all, (size_t)frame_slots * capacity * words * 4)) != PGX_OK) return bail(rc);
+    if ((rc = allgather_locked(c, d_counts_all, (size_t)frame_slots * 4)) != PGX_OK) return bail(rc);
     // phase 3: the image pairs this rank owns (pair list pre-mapped to slots of the gathered buffer)
     pgx_pair *out_l = d_out_all + (size_t)r * pair_slots * capacity;
     rc = pgx_enqueue_match(c, d_desc_all, d_counts_all, capacity, words, d_pairlist_local, n_local_pairs, capacity, out_l);
-    if (rc != PGX_OK) return rc;
+    if (rc != PGX_OK) return bail(rc);
     // phase 4: the fixed-size match lists
-    return allgather_locked(c, d_out_all, (size_t)pair_slots * capacity * sizeof(pgx_pair));
+    rc = allgather_locked(c, d_out_all, (size_t)pair_slots * capacity * sizeof(pgx_pair));
+    return rc == PGX_OK ? rc : bail(rc);
 }
 
 } // extern "C"

@@ -57,3 +57,21 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in text and "pgx_oracle" not in text and "from oracle" not in text \
                     and "import oracle" not in text, os.path.join(dp, f)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """pgx_comm.hip loads librccl at run time; when the file is not there the comm entry points must answer PGX_E_RCCL
+    (round 2's loader called dlerror() twice and dereferenced the NULL of the second call).  PGX_RCCL_LIB points the
+    loader at one file; a child process, because the loader caches its result for the life of the process."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys\n"
+            "L = ctypes.CDLL(%r)\n"
+            "buf = ctypes.create_string_buffer(128)\n"
+            "rc1 = L.pgx_comm_unique_id(buf)\n"
+            "rc2 = L.pgx_comm_unique_id(buf)\n"
+            "print(rc1, rc2)\n" % L.LIB_PATH)
+    env = dict(os.environ, PGX_RCCL_LIB="/nonexistent/librccl.so.1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == [str(L.PGX_E_RCCL)] * 2
