@@ -11,7 +11,14 @@
  *   pinned   : IsPotentialKeypoint / GetIntensityValueIfKeypoint against the three
  *              xUnit known answers (ImageProcessing.Tests/KeypointDetectionTests.cs:10-50)
  *              and Matrix indexer/transposition semantics (LinearAlgebra.Tests/MatrixTests.cs:41-73).
- *   unpinned : BRIEF, NMS, matching, dewarp -- the reference holds no test, golden file or
+ *   pinned by a C# OUTPUT (locations): Detect (a4) on 15pt_star.png -- the blue mask of the reference's
+ *              data/feature_detection_test/output/dotnet_keypoints_backup.bmp (written by the older flow of
+ *              Photogrammetry/Program.cs:116-149, T = 0.2) equals, pixel for pixel, the union of the 10 x 10 squares
+ *              (ResultBuilders.cs:41-54) at this oracle's 126 raw hits; 106 hits own a mask pixel no other hit covers
+ *              and one single non-hit position could be added unnoticed.  The eliminator's (a7) survivors at
+ *              r = (int)(451 * 0.015) sit one per connected component of that mask (30 of 30): a consistency check,
+ *              the image shows every raw hit, not the survivors.  tests/test_oracle.py, tests/golden/make_golden.py.
+ *   unpinned : BRIEF, NMS order, matching, dewarp -- the reference holds no test, golden file or
  *              numeric output for them and its C#/.NET 8 toolchain is absent here, so for those
  *              stages this oracle is "parity unpinned": it is cross-checked only against an
  *              independently written numpy/Python twin (oracle/oracle_np.py) and hand-derived cases.

@@ -126,8 +126,36 @@ def make_star():
     np.savez_compressed(os.path.join(HERE, "star_pair.npz"), **out)
 
 
+def make_dotnet_bmp():
+    """The one numeric artefact the reference holds that its C# path produced:
+    data/feature_detection_test/output/dotnet_keypoints_backup.bmp = 15pt_star.png with a blue square
+    [x-5, x+5) x [y-5, y+5) drawn at every keypoint of the older flow in Photogrammetry/Program.cs:116-149
+    (KeypointDetection(0.2f, 50, 256) on Grayscale.FromRgba; squares of "radius" 5, ResultBuilders.cs:41-54).
+    Stored: the blue mask as packed bits (data, not the file).  Checked here before writing: every non-blue pixel equals
+    the PNG; the mask equals the union of such squares at the oracle's raw FAST hits (the backup shows every hit, i.e. it
+    was written before, or without, the eliminator taking effect)."""
+    from PIL import Image
+    bmp = np.asarray(Image.open("/root/reference/data/feature_detection_test/output/dotnet_keypoints_backup.bmp").convert("RGB"))
+    png = np.asarray(Image.open("/root/reference/data/feature_detection_test/15pt_star.png").convert("RGBA"))
+    assert (png == load_star("15pt_star.png")).all()          # the same file as the star pair's first image
+    assert bmp.shape[:2] == png.shape[:2] == (383, 451)
+    blue = (bmp[..., 0] == 0) & (bmp[..., 1] == 0) & (bmp[..., 2] == 255)
+    assert (bmp[~blue] == png[..., :3][~blue]).all()
+    g = cref.gray(png.astype(np.uint16) * 257)
+    raw = cref.detect(g, np.float32(0.2))
+    m = np.zeros_like(blue)
+    for x, y in zip(raw["x"], raw["y"]):
+        m[max(0, y - 5):y + 5, max(0, x - 5):x + 5] = True
+    assert (m == blue).all()
+    print("dotnet bmp: blue pixels", int(blue.sum()), "raw hits", len(raw))
+    np.savez_compressed(os.path.join(HERE, "dotnet_keypoints_mask.npz"), blue_bits=np.packbits(blue),
+                        shape=np.array(blue.shape, dtype=np.int32), threshold=np.float32(0.2),
+                        radius=np.int32(int(451 * 0.015)), square=np.int32(5))
+
+
 if __name__ == "__main__":
     make_lego()
     make_star()
+    make_dotnet_bmp()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

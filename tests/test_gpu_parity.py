@@ -8,7 +8,7 @@ from oracle import cref, oracle_np as onp
 from photogrammetry_amd import synth
 import photogrammetry_amd as pg
 
-from conftest import pairs_arr, star_rgba64
+from conftest import check_against_dotnet_bmp, pairs_arr, star_rgba64
 
 pytestmark = pytest.mark.gpu
 
@@ -377,6 +377,21 @@ def test_star_pair_end_to_end(engine, star):
     got = pairs_arr(engine.match(descs["a"], descs["b"]))
     assert (got == star["match_ab"]).all()
     engine.set_dewarp_map(None)
+
+
+def test_dotnet_bmp_through_the_abi(engine, star, dotnet_bmp):
+    """The reference's one C#-produced detector output (tests/test_oracle.py::test_dotnet_bmp_pins_detector_locations),
+    checked against the HIP path itself: pgx_gray + pgx_fast for the raw hits, the fused pgx_detect for the survivors of
+    the older flow's parameters (Program.cs:116-149: T = 0.2, r = (int)(451 * 0.015) = 6, no dewarp)."""
+    rgba = star_rgba64(star, "a")
+    engine.set_dewarp_map(None)
+    engine.set_brief_pairs(star["brief_pairs"])
+    engine.set_detect_params(float(dotnet_bmp["threshold"]), int(dotnet_bmp["radius"]))
+    engine.set_capacity(1 << 16, 4096)
+    raw = engine.fast(engine.gray(rgba))
+    kp, _, nraw = engine.detect(rgba, capacity=4096)
+    assert nraw == len(raw)
+    check_against_dotnet_bmp(dotnet_bmp, np.stack([raw["x"], raw["y"]], 1), np.stack([kp["x"], kp["y"]], 1))
 
 
 @pytest.mark.parametrize("W,H,radius,with_map", [(320, 200, 8, True), (640, 360, 20, False), (451, 383, 50, True),

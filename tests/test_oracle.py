@@ -12,7 +12,7 @@ import pytest
 
 from oracle import cref, oracle_np as onp
 
-from conftest import pairs_arr, star_rgba64
+from conftest import check_against_dotnet_bmp, pairs_arr, star_rgba64
 
 
 # ---- reference known answers ----------------------------------------------------------------------
@@ -260,3 +260,23 @@ def test_golden_star_pair(star):
     ka, kb = star["a_kp"], star["b_kp"]
     good = [(kb[k2][0] - ka[k1][0], kb[k2][1] - ka[k1][1]) for k1, k2, d in m if d != cref.INT_MAX]
     assert len(good) == min(len(ka), len(kb))
+
+
+def test_dotnet_bmp_pins_detector_locations(star, dotnet_bmp):
+    """The reference holds ONE numeric output of its C# path: data/feature_detection_test/output/dotnet_keypoints_backup.bmp,
+    15pt_star.png with a blue square at every keypoint of the older flow (Photogrammetry/Program.cs:116-149:
+    KeypointDetection(0.2f, 50, 256), squares of half-width 5).  Its blue mask equals, pixel for pixel, the union of those
+    squares at the oracle's raw FAST hits: 106 of the 126 hits own a pixel of the mask no other hit covers, and exactly one
+    non-hit position could be added without changing it -- so a4 (incl. the duplicated ring offset and the either-direction
+    threshold) is pinned at pixel level by a C# output, and a7's survivors at r = 6 sit one per blue component."""
+    g = cref.gray(star_rgba64(star, "a"))           # K in {0, 1}: the result is the same for Grayscale.FromRgba's scale
+    raw = cref.detect(g, dotnet_bmp["threshold"])
+    kept = raw[cref.nms(raw, int(dotnet_bmp["radius"]))]
+    check_against_dotnet_bmp(dotnet_bmp, np.stack([raw["x"], raw["y"]], 1), np.stack([kept["x"], kept["y"]], 1))
+    # how tightly the mask pins the hits
+    blue, half = dotnet_bmp["blue"], int(dotnet_bmp["square"])
+    cover = np.zeros(blue.shape, dtype=np.int32)
+    for x, y in zip(raw["x"], raw["y"]):
+        cover[max(0, y - half):y + half, max(0, x - half):x + half] += 1
+    own = sum(1 for x, y in zip(raw["x"], raw["y"]) if (cover[max(0, y - half):y + half, max(0, x - half):x + half] == 1).any())
+    assert own == 106
