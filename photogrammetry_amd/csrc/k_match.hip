@@ -36,19 +36,32 @@ constexpr int CNT_N1 = 0, CNT_N2 = 1, CNT_NACC = 2, CNT_N1_ORIG = 3, CNT_N2_ORIG
 struct PairWs {
     uint32_t *rowkey, *colkey, *rows0, *rows1, *cols0, *cols1; // no runtime-indexed arrays: they would live in scratch
     int32_t *mk2, *md;
+    uint32_t *rowbnd, *bndfin; // per row: list bound of the running wide round (atomicMin target) / of the last finished one
     int32_t *cnt;
     uint32_t *skeys;
-    uint16_t *dcache;
+    uint8_t *tail;             // the tail's area (128-byte aligned): layout below
 };
 
 __host__ __device__ inline size_t pow2_ge(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
 
-// per image pair: 8 arrays of S words, counters, sort keys, and the tail's cached distance
-// matrices (u16 D[R][C] and its transpose, R, C <= PGX_TAIL_MAX)
-constexpr size_t DCACHE_WORDS = (size_t)PGX_TAIL_MAX * PGX_TAIL_MAX; // 2 matrices x u16 = 1 word per entry
+// Tail area of one image pair (bytes):
+//   [0, TAIL_MAT_BYTES)        256-bit descriptors: the residual's u8 distance matrix, rows on 128-byte lines (k_tail_rows_fp4 ->
+//                              k_match_gs); other lengths: the u16 matrices D and D^T of the LDS tail (<= PGX_TAIL_FILL_MAX^2 each)
+//   lists  [TAIL_MAX][LCAP]    per residual row: its nearest columns as (distance << 13 | column position), unsorted
+//   lcnt   [TAIL_MAX]          entries emitted per row (may exceed LCAP: then the list is incomplete and not used)
+//   free   [2][S]              gs_fallback's two free lists (any-size path)
+constexpr int LCAP = 256;
+constexpr size_t TAIL_MAT_BYTES = (size_t)PGX_TAIL_MAX * PGX_TAIL_MAX + 128;
+static_assert((size_t)4 * PGX_TAIL_FILL_MAX * PGX_TAIL_FILL_MAX <= TAIL_MAT_BYTES, "D and D^T of the generic tail share the matrix area");
+constexpr size_t TAIL_LISTS_OFF = TAIL_MAT_BYTES;
+constexpr size_t TAIL_LCNT_OFF = TAIL_LISTS_OFF + (size_t)PGX_TAIL_MAX * LCAP * 4;
+constexpr size_t TAIL_FREE_OFF = TAIL_LCNT_OFF + (size_t)PGX_TAIL_MAX * 4;
+__host__ __device__ inline size_t tail_words(int S) { return (TAIL_FREE_OFF + (size_t)8 * S + 128) / 4; }
+
+// per image pair: 10 arrays of S words, counters, sort keys, the tail area
 __host__ __device__ inline size_t pair_ws_words(int S)
 {
-    return (size_t)8 * S + CNT_WORDS + pow2_ge((size_t)(S > 1 ? S : 1)) + DCACHE_WORDS;
+    return (size_t)10 * S + CNT_WORDS + pow2_ge((size_t)(S > 1 ? S : 1)) + tail_words(S);
 }
 
 __device__ __forceinline__ PairWs pair_ws(uint32_t *ws, int m, int S)
@@ -60,11 +73,16 @@ __device__ __forceinline__ PairWs pair_ws(uint32_t *ws, int m, int S)
     p.cols0 = b + 4 * (size_t)S; p.cols1 = b + 5 * (size_t)S;
     p.mk2 = reinterpret_cast<int32_t *>(b + 6 * (size_t)S);
     p.md = reinterpret_cast<int32_t *>(b + 7 * (size_t)S);
-    p.cnt = reinterpret_cast<int32_t *>(b + 8 * (size_t)S);
-    p.skeys = b + 8 * (size_t)S + CNT_WORDS;
-    p.dcache = reinterpret_cast<uint16_t *>(p.skeys + pow2_ge((size_t)(S > 1 ? S : 1)));
+    p.rowbnd = b + 8 * (size_t)S; p.bndfin = b + 9 * (size_t)S;
+    p.cnt = reinterpret_cast<int32_t *>(b + 10 * (size_t)S);
+    p.skeys = b + 10 * (size_t)S + CNT_WORDS;
+    uint32_t *t = p.skeys + pow2_ge((size_t)(S > 1 ? S : 1));
+    p.tail = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(t) + 127) & ~(uintptr_t)127);
     return p;
 }
+__device__ __forceinline__ uint32_t *tail_lists(const PairWs &p) { return reinterpret_cast<uint32_t *>(p.tail + TAIL_LISTS_OFF); }
+__device__ __forceinline__ uint32_t *tail_lcnt(const PairWs &p) { return reinterpret_cast<uint32_t *>(p.tail + TAIL_LCNT_OFF); }
+__device__ __forceinline__ uint32_t *tail_free(const PairWs &p) { return reinterpret_cast<uint32_t *>(p.tail + TAIL_FREE_OFF); }
 
 __global__ __launch_bounds__(256) void k_match_init(uint32_t *ws, const int32_t *__restrict__ counts,
                                                     const int32_t *__restrict__ pairlist, int S, int max_n,
@@ -82,6 +100,8 @@ __global__ __launch_bounds__(256) void k_match_init(uint32_t *ws, const int32_t 
         p.cols0[i] = (uint32_t)i;
         p.mk2[i] = -1;
         p.md[i] = PGX_DIST_NONE;
+        p.rowbnd[i] = PGX_KEY_NONE;
+        p.bndfin[i] = PGX_KEY_NONE;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         p.cnt[CNT_N1] = n1; p.cnt[CNT_N2] = n2; p.cnt[CNT_NACC] = 0;
@@ -223,7 +243,7 @@ __device__ void select_compact_wg(PairWs p, int parity, uint32_t *wsum)
         uint32_t o = ex;
         for (int r = b; r < e; r++) {
             const uint32_t i = rows[r];
-            if (p.mk2[i] < 0) { nrows[o++] = i; p.rowkey[i] = PGX_KEY_NONE; }
+            if (p.mk2[i] < 0) { nrows[o++] = i; p.rowkey[i] = PGX_KEY_NONE; p.bndfin[i] = p.rowbnd[i]; p.rowbnd[i] = PGX_KEY_NONE; }
         }
         __syncthreads();
         if (tid == 0) { p.cnt[CNT_NACC] += n1 - (int)tot; p.cnt[CNT_N1] = (int)tot; }
@@ -371,8 +391,8 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nth >> 6;
     const int R = p.cnt[CNT_N1], C = p.cnt[CNT_N2];
     const int Cs = (C + 7) & ~7, Rs = (R + 7) & ~7;       // row strides of the two cached matrices (16-B rows)
-    uint16_t *D = p.dcache;                                // D[i][j], i < R, j < Cs
-    uint16_t *DT = p.dcache + (size_t)PGX_TAIL_MAX * PGX_TAIL_MAX; // DT[j][i]
+    uint16_t *D = reinterpret_cast<uint16_t *>(p.tail);   // D[i][j], i < R, j < Cs
+    uint16_t *DT = D + (size_t)PGX_TAIL_FILL_MAX * PGX_TAIL_FILL_MAX; // DT[j][i]
     uint32_t *rl = lds, *cl = rl + TAIL_MAX, *rbest = cl + TAIL_MAX, *cbest = rbest + TAIL_MAX;
     uint32_t *rdl = cbest + TAIL_MAX, *cdl = rdl + TAIL_MAX;
     uint8_t *ralive = reinterpret_cast<uint8_t *>(cdl + TAIL_MAX), *calive = ralive + TAIL_MAX;
@@ -604,7 +624,7 @@ __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uin
 __device__ __forceinline__ int tail_row_stride(int C) { return (C + 127) & ~127; }
 __device__ __forceinline__ uint8_t *tail_matrix(const PairWs &p)
 {
-    return reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(p.dcache) + 127) & ~(uintptr_t)127);
+    return p.tail;
 }
 
 #include "k_match_tail.inc"
@@ -655,15 +675,18 @@ void pgx_launch_match_wide(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, 
                            dim3(256), 0, s, ws, d_counts, d_pairlist, plan.stride, plan.max_n, status);
     }
     for (int r = 0; r < plan.rounds_mfma; r++) {
+        // 256-bit descriptors: the first round runs for every image pair whatever its size -- besides the mutual-nearest
+        // edges it yields every row's list bound (k_ham_fp4), without which the tail has no tier-1 lists
+        const int skip = (plan.words == 8 && r == 0) ? 0 : plan.skip_below;
         {
             ProfScope ps(ctx, "ham_argmin", s);
-            if (plan.words == 8) pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan);   // 256-bit descriptors: the matrix pipe
-            else launch_rounds_valu<0>(s, ws, d_desc, d_pairlist, plan);                // any other length: xor + popcount
+            if (plan.words == 8) pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan, skip);   // 256-bit descriptors: the matrix pipe
+            else launch_rounds_valu<0>(s, ws, d_desc, d_pairlist, plan);                      // any other length: xor + popcount
         }
         {
             ProfScope ps(ctx, "match_select", s);
             hipLaunchKernelGGL(k_match_select, dim3(plan.M), dim3(SEL_NT), 0, s, ws, plan.stride,
-                               reinterpret_cast<unsigned long long *>(status + 4) + (r < PGX_MAX_WIDE_ROUNDS ? r : PGX_MAX_WIDE_ROUNDS - 1), plan.skip_below);
+                               reinterpret_cast<unsigned long long *>(status + 4) + (r < PGX_MAX_WIDE_ROUNDS ? r : PGX_MAX_WIDE_ROUNDS - 1), skip);
         }
     }
 }

@@ -160,6 +160,7 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     plan.skip_below = words == 8 ? PGX_TAIL_MAX : PGX_TAIL_FILL_MAX;
     for (int n = plan.max_n; n > plan.skip_below && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
     if (plan.rounds_mfma > 0 && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS) plan.rounds_mfma++;
+    if (words == 8 && plan.rounds_mfma == 0) plan.rounds_mfma = 1; // small sets too: the round that yields the tail's list bounds
     HIPCHK(c, hipMemsetAsync(c->d_status + 4, 0, PGX_MAX_WIDE_ROUNDS * 8, c->stream));
     if (M <= CHUNK || c->prof_serial) { // everything in order on the context's stream
         for (int m0 = 0; m0 < M; m0 += CHUNK) {
