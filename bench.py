@@ -439,7 +439,7 @@ def worker(args):
         eng.check_status()
         if rank == 0:
             kern_alone = kernel_table(eng, k_alone)
-    log('tail debug (rounds, row re-reads, re-read passes, proposals) per image pair:', [x / float(max(1, args.steps * max(1, len(job.my_pairs)))) for x in dbg[3:7]])
+    log('tail debug per image pair (0, 0, 0, rounds, column scans, list steps, free rows, parked rows):', [round(x / float(max(1, args.steps * max(1, len(job.my_pairs)))), 2) for x in dbg])
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:

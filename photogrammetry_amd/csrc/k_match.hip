@@ -28,6 +28,9 @@
 //                     sort (bitonic, LDS), the N1 output entries
 #include "pgx_internal.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace {
 
 constexpr int SEL_NT = 1024;
@@ -45,17 +48,20 @@ struct PairWs {
 __host__ __device__ inline size_t pow2_ge(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
 
 // Tail area of one image pair (bytes):
-//   [0, TAIL_MAT_BYTES)        256-bit descriptors: the residual's u8 distance matrix, rows on 128-byte lines (k_tail_rows_fp4 ->
-//                              k_match_gs); other lengths: the u16 matrices D and D^T of the LDS tail (<= PGX_TAIL_FILL_MAX^2 each)
-//   lists  [TAIL_MAX][LCAP]    per residual row: its nearest columns as (distance << 13 | column position), unsorted
-//   lcnt   [TAIL_MAX]          entries emitted per row (may exceed LCAP: then the list is incomplete and not used)
-//   free   [2][S]              gs_fallback's two free lists (any-size path)
-constexpr int LCAP = 256;
-constexpr size_t TAIL_MAT_BYTES = (size_t)PGX_TAIL_MAX * PGX_TAIL_MAX + 128;
-static_assert((size_t)4 * PGX_TAIL_FILL_MAX * PGX_TAIL_FILL_MAX <= TAIL_MAT_BYTES, "D and D^T of the generic tail share the matrix area");
-constexpr size_t TAIL_LISTS_OFF = TAIL_MAT_BYTES;
-constexpr size_t TAIL_LCNT_OFF = TAIL_LISTS_OFF + (size_t)PGX_TAIL_MAX * LCAP * 4;
-constexpr size_t TAIL_FREE_OFF = TAIL_LCNT_OFF + (size_t)PGX_TAIL_MAX * 4;
+//   256-bit descriptors (k_res_lists -> k_match_gs):
+//     lists  [TAIL_MAX][2][LSUB]  per residual row and lane half: the row's nearest columns as (distance << 13 | column position)
+//     lcnt   [TAIL_MAX][2]        entries per sub-list; above LSUB - LMARGIN: overflowed, the row's list is not used
+//     lcnt2  [TAIL_MAX][16] u8    k_match_gs's later stretches of a row's list: 16 groups of up to 16 entries over the same slots
+//   other lengths: the u16 matrices D and D^T of the LDS tail (<= PGX_TAIL_FILL_MAX^2 each), over the same bytes
+//   free   [2][S]                 gs_fallback's two free lists (any-size path)
+constexpr int LSUB = 128;    // slots per sub-list
+constexpr int LMARGIN = 16;  // a lane appends up to 16 entries between two overflow checks
+constexpr size_t TAIL_LISTS_OFF = 0;
+constexpr size_t TAIL_LCNT_OFF = TAIL_LISTS_OFF + (size_t)PGX_TAIL_MAX * 2 * LSUB * 4;
+constexpr size_t TAIL_GEN_BYTES = (size_t)4 * PGX_TAIL_FILL_MAX * PGX_TAIL_FILL_MAX;
+constexpr size_t TAIL_LCNT2_OFF = TAIL_LCNT_OFF + (size_t)PGX_TAIL_MAX * 2 * 4;   // k_match_gs: u8 [TAIL_MAX][16], entries per group of a stretch
+constexpr size_t TAIL_LIST_BYTES = TAIL_LCNT2_OFF + (size_t)PGX_TAIL_MAX * 16;
+constexpr size_t TAIL_FREE_OFF = ((TAIL_GEN_BYTES > TAIL_LIST_BYTES ? TAIL_GEN_BYTES : TAIL_LIST_BYTES) + 127) & ~(size_t)127;
 __host__ __device__ inline size_t tail_words(int S) { return (TAIL_FREE_OFF + (size_t)8 * S + 128) / 4; }
 
 // per image pair: 10 arrays of S words, counters, sort keys, the tail area
@@ -82,6 +88,7 @@ __device__ __forceinline__ PairWs pair_ws(uint32_t *ws, int m, int S)
 }
 __device__ __forceinline__ uint32_t *tail_lists(const PairWs &p) { return reinterpret_cast<uint32_t *>(p.tail + TAIL_LISTS_OFF); }
 __device__ __forceinline__ uint32_t *tail_lcnt(const PairWs &p) { return reinterpret_cast<uint32_t *>(p.tail + TAIL_LCNT_OFF); }
+__device__ __forceinline__ uint32_t *tail_lcnt2(const PairWs &p) { return reinterpret_cast<uint32_t *>(p.tail + TAIL_LCNT2_OFF); }
 __device__ __forceinline__ uint32_t *tail_free(const PairWs &p) { return reinterpret_cast<uint32_t *>(p.tail + TAIL_FREE_OFF); }
 
 __global__ __launch_bounds__(256) void k_match_init(uint32_t *ws, const int32_t *__restrict__ counts,
@@ -617,18 +624,8 @@ __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uin
 
 } // namespace
 
-// The residual byte matrix of an image pair (k_tail_rows* write it, k_match_gs reads it): rows start on 128-byte lines.
-// The rows kernel is bound by its HBM writes, and a store instruction of it covers 16 rows x 64 bytes: with rows on line
-// boundaries the two halves of a line come from neighbouring wavefronts of one workgroup and leave L2 as whole lines
-// (tools/probe/write_pattern.hip: 120 -> 96 us for 385 MB in that pattern).
-__device__ __forceinline__ int tail_row_stride(int C) { return (C + 127) & ~127; }
-__device__ __forceinline__ uint8_t *tail_matrix(const PairWs &p)
-{
-    return p.tail;
-}
-
-#include "k_match_tail.inc"
 #include "k_match_mfma.inc"
+#include "k_match_tail.inc"
 
 size_t pgx_match_ws_bytes(int M, int stride) { return (size_t)M * pair_ws_words(stride) * 4; }
 
@@ -697,7 +694,7 @@ void pgx_launch_match_rows(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, 
     if (plan.M <= 0 || plan.words != 8) return;
     uint32_t *ws = reinterpret_cast<uint32_t *>(wsv);
     ProfScope ps(ctx, "tail_rows", s);
-    hipLaunchKernelGGL(k_tail_rows_fp4, dim3(PGX_TAIL_MAX / TM_ROWS, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
+    hipLaunchKernelGGL(k_res_lists, dim3(PGX_TAIL_MAX / RL_ROWS, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
 }
 
 void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_pairlist,
@@ -709,7 +706,20 @@ void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc
     if (plan.words == 8) {
         const size_t n2p = pow2_ge((size_t)(plan.max_n > 1 ? plan.max_n : 1));
         const size_t key_cap = n2p <= 8192 ? n2p : 0; // sort keys in LDS up to 32 KiB, else in the workspace
-        hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(GS_NT), key_cap * 4, s, ws, d_desc, d_pairlist, plan.stride, d_out,
+        const size_t dyn = (key_cap > (size_t)2 * PGX_TAIL_MAX ? key_cap : (size_t)2 * PGX_TAIL_MAX) * 4; // the residual's column and row indices during the matching, then sort keys
+        static bool attr_set = false;
+        if (!attr_set) { // static + dynamic LDS may exceed 64 KiB
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_gs), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            attr_set = true;
+            if (getenv("PGX_DEBUG_OCC")) {
+                int nb = -1;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_match_gs), GS_NT, dyn);
+                hipFuncAttributes fa;
+                (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_match_gs));
+                fprintf(stderr, "k_match_gs: %d blocks/CU at dyn %zu; static LDS %zu regs %d scratch %zu\n", nb, dyn, fa.sharedSizeBytes, fa.numRegs, fa.localSizeBytes);
+            }
+        }
+        hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(GS_NT), dyn, s, ws, d_desc, d_pairlist, plan.stride, d_out,
                            (uint32_t)key_cap, status);
     } else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out, status);
 }
