@@ -52,9 +52,8 @@ THRESH = 0.1
 SEQ_FRAMES = 64
 # The distance kernel runs on the block-scaled FP4 matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4, e2m1 operands
 # +-1, exact): its dense peak is the FP6/FP4 figure of /opt/skills/guides/MI355X_MICROARCH.md (4x the 2.5 PF bf16 rate).
-# PGX_HAM_FP4=0 selects the int8 kernel of the first half of round 2, whose pipe peaks at 5.0e15.
-MFMA_FP4 = os.environ.get("PGX_HAM_FP4", "2") != "0"
-I8_MFMA_PEAK_OPS = 10.0e15 if MFMA_FP4 else 5.0e15   # name kept: operations of the 256-bit +-1 contraction per second
+MFMA_FP4 = True
+I8_MFMA_PEAK_OPS = 10.0e15   # name kept from round 1: operations of the 256-bit +-1 contraction per second (dense FP4 peak)
 HBM_PEAK = 8.0e12
 TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
@@ -72,8 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--frames", type=int, default=SEQ_FRAMES, help="frames per sequence (all ordered pairs are matched)")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-procs", type=int, default=16,
-                    help="processes of the multi-core CPU bar (0/1 = skip); 16 = a one-GPU box's CPU share")
+    ap.add_argument("--cpu-procs", type=int, default=0,
+                    help="processes of the multi-core CPU bar: 0 = one per CPU this process may run on (os.sched_getaffinity), 1 = skip")
     ap.add_argument("--no-dewarp", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs / host_api objects (N = 1)")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
@@ -215,6 +214,14 @@ def _cpu_pair_worker(path):
     return len(descs[0]) * len(descs[1]), time.time() - t0
 
 
+def _cpu_warm_worker(_):
+    """Start-up of one worker process: the imports and the oracle library, nothing timed."""
+    import numpy as np  # noqa: F401
+    from oracle import cref
+    cref.lib()
+    return os.getpid()
+
+
 def cpu_multicore(frames, dmap, pairs, nproc):
     """nproc processes, each running the optimised single-thread pipeline on the sample pair at the same time."""
     import concurrent.futures
@@ -235,7 +242,7 @@ def cpu_multicore(frames, dmap, pairs, nproc):
         os.environ["ROCR_VISIBLE_DEVICES"] = ""
         ctx = multiprocessing.get_context("spawn")
         with concurrent.futures.ProcessPoolExecutor(max_workers=nproc, mp_context=ctx) as ex:
-            list(ex.map(_cpu_pair_worker, [path] * nproc))           # start-up and first touch
+            list(ex.map(_cpu_warm_worker, range(4 * nproc), chunksize=1))   # start every worker (imports, dlopen); not timed
             os.environ.clear()
             os.environ.update(saved)
             t0 = time.time()
@@ -282,6 +289,47 @@ def cpu_baseline(frames, dmap, pairs, sample_n):
                       "Theta(N^3) greedy match of the first %dx%d keypoints (%.2f s); C restatement of the C# "
                       "(hardware popcount, so faster than the real BigInteger loop)" % (t_detect, n1, n2, t_match),
             "detect_s_per_frame": t_detect / 2, "match_s": t_match, "match_n": [n1, n2]}
+
+
+# ---------------------------------------------------------------------------------------------------
+# the timed job checks itself (rank 0, after the timed region, outside it)
+# ---------------------------------------------------------------------------------------------------
+
+def verify_job(job, pair_list, host_frame0, dmap, pairs_tbl, FS):
+    """Compare the job that was just timed with the CPU oracle: three image pairs (first, middle, last) -- their whole match
+    lists against the oracle's sorted-edge-scan matcher on the GPU's own descriptors -- and one frame (global frame 0:
+    keypoints, grey values by bit pattern, descriptors) against the oracle's detect chain on the host copy of that frame.
+    The oracle is the checker here, never the thing measured."""
+    import numpy as np
+    from oracle import cref
+    counts = job.counts()
+    M = len(pair_list)
+    res = {"pairs": [], "frames": [], "ok": True}
+    for p in sorted({0, M // 2, M - 1}):
+        a, b = pair_list[p]
+        da = job.descriptors(a).cpu().numpy().view(np.uint32)[:counts[a]]
+        db = job.descriptors(b).cpu().numpy().view(np.uint32)[:counts[b]]
+        got = job.matches(p).cpu().numpy()[:counts[a]]
+        exp = cref.match_sorted(da, db)
+        ok = bool((got[:, 0] == exp["k1"]).all() and (got[:, 1] == exp["k2"]).all() and (got[:, 2] == exp["dist"]).all())
+        res["pairs"].append({"pair": [int(a), int(b)], "n1": int(counts[a]), "n2": int(counts[b]), "ok": ok})
+        res["ok"] &= ok
+    if job.my_frames and job.my_frames[0] == 0 and host_frame0 is not None:   # rank 0 owns global frame 0 = the base frame itself
+        ident = np.stack(np.meshgrid(np.arange(W), np.arange(H)), axis=2).astype(np.int32)
+        g = cref.gray(cref.apply_distortion(host_frame0, dmap if dmap is not None else ident))
+        raw = cref.detect(g, np.float32(THRESH))
+        kept = raw[cref.nms(raw, RADIUS)][:NKP]
+        edesc = cref.brief(g, np.stack([kept["x"], kept["y"]], 1), pairs_tbl)
+        kp = job.kp_l[0].cpu().numpy()[:counts[0]]
+        desc = job.descriptors(0).cpu().numpy().view(np.uint32)[:counts[0]]
+        ok = bool(len(kept) == counts[0] and int(job.nraw_l[0].item()) == len(raw)
+                  and (kp[:, 0] == kept["x"]).all() and (kp[:, 1] == kept["y"]).all() and (kp[:, 2] == kept["fast_score"]).all()
+                  and kp[:, 3].view(np.float32).tobytes() == kept["value"].tobytes() and (desc == edesc).all())
+        res["frames"].append({"frame": 0, "raw_hits": int(len(raw)), "keypoints": int(len(kept)), "ok": ok})
+        res["ok"] &= ok
+    res["what"] = ("after the timed region: match lists of the first / middle / last image pair vs the oracle's sorted-edge-scan matcher, "
+                   "and frame 0's keypoints, grey values and descriptors vs the oracle's detect chain; bit-exact or the run fails")
+    return res
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -439,7 +487,7 @@ def worker(args):
         eng.check_status()
         if rank == 0:
             kern_alone = kernel_table(eng, k_alone)
-    log('tail debug per image pair (0, 0, 0, rounds, column scans, list steps, free rows, parked rows):', [round(x / float(max(1, args.steps * max(1, len(job.my_pairs)))), 2) for x in dbg])
+    log('tail debug (rounds, row re-reads, re-read passes, proposals) per image pair:', [round(x / float(max(1, args.steps * max(1, len(job.my_pairs)))), 2) for x in dbg[3:7]])
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -478,6 +526,11 @@ def worker(args):
 
     rc = 0
     if rank == 0:
+        t_v = time.time()
+        verified = verify_job(job, pair_list, host_base0, dmap, pairs, FS)
+        log("verification of the timed job took %.1fs: %s" % (time.time() - t_v, "ok" if verified["ok"] else "MISMATCH"))
+        if not verified["ok"]:
+            rc = 4
         F_l, M_l = len(job.my_frames), len(job.my_pairs)
         # per-kernel times: the timed region brackets the metric's kernel only; the other groups come from the stand-alone pass
         kern = dict(kern_alone)
@@ -570,17 +623,17 @@ def worker(args):
                        "jobs_in_flight": NI,
                        "rehearsal_on_one_gpu_with_gloo": rehearse},
             "roofline": rooflines.get(dominant),
+            "verified": verified,
             "mfma": mfma,
             "c_abi_comm": c_abi,
             "traffic_note": traffic_src,
             "rooflines": rooflines,
             "kernels": kern,
-            "kernels_note": "ham_argmin: HIP events over the timed region (live); every other group: the untimed stand-alone pass "
-                            "(bracketing every launch costs 0.6 ms per step, so the timed region brackets the metric's kernel only)",
+            "kernels_note": "kernels: ham_argmin = HIP events over the TIMED steps (live: the matcher stages of consecutive chunks of 256 image "
+                            "pairs run side by side on three streams, so its bracket is stretched by the co-resident stages); every other "
+                            "group is taken from kernels_standalone (bracketing every launch costs 0.6 ms per step, so the timed region "
+                            "brackets the metric's kernel only).  kernels_standalone: the same steps again, untimed, stages in order on one stream",
             "kernels_standalone": kern_alone,
-            "kernels_note": "kernels: rank 0's HIP events around every launch of the TIMED steps -- the matcher stages of consecutive chunks of "
-                            "128 image pairs run side by side on four streams, so their brackets overlap and the sum exceeds ms_per_step; "
-                            "kernels_standalone: the same steps again, untimed, stages in order on one stream",
             "detect": {"ms_per_step": detect_ms, "frames_per_s": F_l / (detect_ms * 1e-3) if detect_ms else None},
             "match_only": {"ms_per_step_sum_of_kernels": match_ms,
                            "wall_ms_per_step": max(step_ms - detect_ms, 0.0) if detect_ms else None,
@@ -606,14 +659,14 @@ def worker(args):
             cb["cpu_model"] = cpu_model()
             cb["host_logical_cpus"] = os.cpu_count()
             cb["cpus_available_to_this_process"] = len(os.sched_getaffinity(0))
-            if args.cpu_procs > 1:
+            if args.cpu_procs != 1:
                 try:
-                    nproc = min(args.cpu_procs, len(os.sched_getaffinity(0)))
+                    avail = len(os.sched_getaffinity(0))
+                    nproc = avail if args.cpu_procs <= 0 else min(args.cpu_procs, avail)
                     cb["optimised_multicore"] = cpu_multicore(sample, dmap if dmap is not None else ident, pairs, nproc)
-                    cb["optimised_multicore"]["note"] = ("%d worker processes = the CPU share of a one-GPU box on this pool; the host "
-                                                         "has %d logical CPUs (%s): linear extrapolation to all of them = %.3g pairs/s"
-                                                         % (nproc, os.cpu_count(), cb["cpu_model"],
-                                                            cb["optimised_multicore"]["value"] * (os.cpu_count() or nproc) / nproc))
+                    cb["optimised_multicore"]["note"] = ("measured, not extrapolated: %d worker processes at once = every CPU this process may "
+                                                         "run on (%d of the host's %d logical CPUs, %s), each through the whole sample pair"
+                                                         % (nproc, avail, os.cpu_count(), cb["cpu_model"]))
                 except Exception as e:   # a report nicety, never a reason to lose the bench line
                     log("multi-core CPU bar skipped: %r" % (e,))
             result["cpu_baseline"] = cb
@@ -807,6 +860,18 @@ def host_api_timing(torch, pg, np, eng, base, dev):
         res[label] = {"pgx_detect_ms_per_frame": t_det * 1e3, "pgx_match_ms_per_pair": t_match * 1e3,
                       "pairs_per_s_one_pair_at_a_time": len(d0) * len(d1) / (2 * t_det + t_match),
                       "keypoints": [len(d0), len(d1)]}
+        if label == "pinned":
+            # the batched host entry point: 64 image pairs (the same two sets, both directions) per pgx_match_batch call
+            plb = [(0, 1), (1, 0)] * 32
+            eng.match_batch([d0, d1], plb)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.match_batch([d0, d1], plb)
+            t_b = (time.perf_counter() - t0) / reps
+            res["pgx_match_batch"] = {"image_pairs_per_call": len(plb), "ms_per_call": t_b * 1e3, "ms_per_pair": t_b * 1e3 / len(plb),
+                                      "descriptor_pairs_per_s": len(plb) * len(d0) * len(d1) / t_b,
+                                      "what": "pgx_match_batch from host arrays: one upload (2 descriptor sets), one enqueue of the batched "
+                                              "matcher, one download of 64 match lists"}
     frame_mb = f0.nbytes / 1e6
     res["note"] = ("synchronous host-buffer calls, one frame / one image pair at a time: each pgx_detect uploads %.1f MB (PCIe Gen5 x16 "
                    "spec 63 GB/s = %.2f ms at best) and waits; the batched _dev entry points above are the throughput path"

@@ -95,7 +95,8 @@ int pgx_set_detect_params(pgx_ctx *ctx, float threshold, int suppression_radius)
 int pgx_set_capacity(pgx_ctx *ctx, int max_raw_per_frame, int max_keypoints_per_frame);
 /* Image pairs per workspace chunk of pgx_match_batch_dev / pgx_sequence_step_dev (default 256, [16, 4096]).  A job with
  * more pairs goes through in chunks whose stages overlap on the device; the chunk bounds the matcher's workspace
- * (about 4.2 MiB per image pair at 4096 descriptors a side, three chunks resident) and should be large enough that one
+ * (about 4.4 MiB per image pair at 4096 descriptors a side -- 4 MiB of it the residual's distance matrix --, three chunks resident:
+ * 3.4 GB at the default; the largest chunk, 4096 pairs, takes 54 GB) and should be large enough that one
  * chunk's per-pair finish fills the chip (one workgroup per pair: 256 pairs = 256 CUs).  Results do not depend on it.
  * No reference counterpart (KeypointMatching.cs:14-69 matches one pair per call). */
 int pgx_set_match_chunk(pgx_ctx *ctx, int image_pairs_per_chunk);
@@ -121,6 +122,16 @@ int pgx_nms(pgx_ctx *ctx, const pgx_keypoint *kps, int n, int W, int H,
  * n2 == 0 < n1.  words = uint32 words per descriptor. */
 int pgx_match(pgx_ctx *ctx, const uint32_t *desc1, int n1, const uint32_t *desc2, int n2,
               int words, pgx_pair *out);
+
+/* KeypointMatching.MatchKeypoints for n_pairs image pairs in ONE call, host buffers ("Call sites": the batched
+ * form a P/Invoke host with managed arrays calls instead of n_pairs x pgx_match -- one upload, one enqueue of the batched
+ * matcher, one download).  descs[f] = frame f's descriptors [counts[f]][words] (may be NULL when counts[f] == 0);
+ * pair_list [n_pairs][2] = (frame_a, frame_b).  out receives the lists back to back in pair order: list m has counts[a_m]
+ * entries and starts at out_offsets[m] (out_offsets [n_pairs + 1], optional; the caller sizes out as the sum of counts[a_m]).
+ * A pair with counts[b] == 0 < counts[a] gets counts[a] entries (0, 0, PGX_DIST_NONE) and the call returns PGX_E_EMPTY_SET
+ * after all lists are written (the reference would have thrown at that pair, KeypointMatching.cs:61). */
+int pgx_match_batch(pgx_ctx *ctx, const uint32_t *const *descs, const int32_t *counts, int n_frames, int words,
+                    const int32_t *pair_list, int n_pairs, pgx_pair *out, int64_t *out_offsets);
 
 /* ---- fused host entry point: dewarp -> gray -> detect -> NMS -> BRIEF for one image ---- */
 /* The chain of TestService.BuildKeypointDetectorPipeline (TestService.cs:137-152).

@@ -7,6 +7,7 @@
 // because its only constructor recomputes BRIEF from the image (Keypoint.cs:17-27).
 using System;
 using System.Collections.Generic;
+using System.Linq;
 using System.Numerics;
 using System.Runtime.InteropServices;
 using ImageProcessing.Abstractions;
@@ -118,6 +119,36 @@ public sealed unsafe class GpuKeypointMatching
         var result = new List<KeypointPair>(keypoints1.Count);
         for (var i = 0; i < keypoints1.Count; i++)
             result.Add(new KeypointPair { Keypoint1 = keypoints1[pairs[i].K1], Keypoint2 = keypoints2[pairs[i].K2], Distance = pairs[i].Dist });
+        return result;
+    }
+
+    /// <summary>MatchKeypoints for many image pairs in ONE native call (pgx_match_batch): one upload, one enqueue, one download.
+    /// One pair per call (above) leaves the GPU idle between calls; a host that has several keypoint lists should use this.</summary>
+    public List<List<KeypointPair>> MatchKeypointsBatch(List<List<Keypoint>> frames, List<(int A, int B)> pairs, int words = 8)
+    {
+        var packed = frames.Select(f => Pack(f, words)).ToArray();
+        var counts = frames.Select(f => f.Count).ToArray();
+        var pl = pairs.SelectMany(p => new[] { p.A, p.B }).ToArray();
+        var total = pairs.Sum(p => frames[p.A].Count);
+        var o = new PgxPair[Math.Max(1, total)];
+        var offs = new long[pairs.Count + 1];
+        var handles = packed.Select(a => GCHandle.Alloc(a, GCHandleType.Pinned)).ToArray();
+        try
+        {
+            var ptrs = handles.Select(h => (IntPtr)h.AddrOfPinnedObject()).ToArray();
+            fixed (IntPtr* pp = ptrs) fixed (int* c = counts) fixed (int* l = pl) fixed (PgxPair* po = o) fixed (long* off = offs)
+                PgxNative.Check(_ctx.Handle, PgxNative.pgx_match_batch(_ctx.Handle, (uint**)pp, c, frames.Count, words, l, pairs.Count, po, off));
+        }
+        finally { foreach (var h in handles) h.Free(); }
+        var result = new List<List<KeypointPair>>(pairs.Count);
+        for (var m = 0; m < pairs.Count; m++)
+        {
+            var (a, b) = pairs[m];
+            var list = new List<KeypointPair>(frames[a].Count);
+            for (var i = offs[m]; i < offs[m + 1]; i++)
+                list.Add(new KeypointPair { Keypoint1 = frames[a][o[i].K1], Keypoint2 = frames[b][o[i].K2], Distance = o[i].Dist });
+            result.Add(list);
+        }
         return result;
     }
 

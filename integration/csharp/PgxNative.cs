@@ -36,6 +36,9 @@ internal static unsafe class PgxNative
     [DllImport(Lib)] public static extern int pgx_brief(IntPtr ctx, float* gray, int w, int h, PgxKeypoint* kps, int n, uint* desc);
     [DllImport(Lib)] public static extern int pgx_nms(IntPtr ctx, PgxKeypoint* kps, int n, int w, int h, int* order, out int nOut);
     [DllImport(Lib)] public static extern int pgx_match(IntPtr ctx, uint* d1, int n1, uint* d2, int n2, int words, PgxPair* o);
+    // many image pairs, managed arrays, one call: descs[f] -> frame f's descriptors, pairList [m][2], lists back to back in `o`
+    [DllImport(Lib)] public static extern int pgx_match_batch(IntPtr ctx, uint** descs, int* counts, int nFrames, int words,
+                                                              int* pairList, int nPairs, PgxPair* o, long* outOffsets);
     [DllImport(Lib)] public static extern int pgx_detect(IntPtr ctx, ushort* rgba64, int w, int h, PgxKeypoint* kp, uint* desc,
                                                          int capacity, out int n, out int nRaw);
 

@@ -182,6 +182,27 @@ class Engine:
         self._chk(self._L.pgx_match(self._h, _ptr(d1), len(d1), _ptr(d2), len(d2), int(words), _ptr(out)))
         return out[:len(d1)].copy()
 
+    def match_batch(self, descs, pair_list):
+        """pgx_match_batch: descs = list of [n_f][words] arrays (one per frame), pair_list = [(a, b), ...] -> list of
+        PAIR_DTYPE arrays, one per image pair, in the reference's emission order.  Raises ArgumentOutOfRangeException
+        (after all lists are computed) when some pair has an empty second set."""
+        F = len(descs)
+        arrs = [np.ascontiguousarray(d, dtype=np.uint32) for d in descs]
+        words = next((a.shape[1] for a in arrs if a.ndim == 2 and a.shape[0]), 8)
+        counts = np.array([len(a) for a in arrs], dtype=np.int32)
+        ptrs = (C.c_void_p * max(1, F))(*[a.ctypes.data if len(a) else None for a in arrs])
+        pl = np.ascontiguousarray(pair_list, dtype=np.int32).reshape(-1, 2)
+        M = len(pl)
+        total = int(sum(int(counts[a]) for a, _ in pl))
+        out = np.zeros(max(1, total), dtype=PAIR_DTYPE)
+        offs = np.zeros(M + 1, dtype=np.int64)
+        rc = self._L.pgx_match_batch(self._h, ptrs, _ptr(counts), F, int(words), _ptr(pl), M, _ptr(out), _ptr(offs))
+        lists = [out[offs[m]:offs[m + 1]].copy() for m in range(M)]
+        if rc == _lib.PGX_E_EMPTY_SET:
+            self.last_batch_lists = lists   # all lists are valid; the reference would have thrown at the empty pair
+        self._chk(rc)
+        return lists
+
     def detect(self, rgba64, capacity=8192):
         a = np.ascontiguousarray(rgba64, dtype=getattr(self, "_src_dtype", np.uint16))
         kp = np.zeros(capacity, dtype=KEYPOINT_DTYPE)

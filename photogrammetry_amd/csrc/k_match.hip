@@ -28,9 +28,6 @@
 //                     sort (bitonic, LDS), the N1 output entries
 #include "pgx_internal.h"
 
-#include <cstdio>
-#include <cstdlib>
-
 namespace {
 
 constexpr int SEL_NT = 1024;
@@ -39,35 +36,23 @@ constexpr int CNT_N1 = 0, CNT_N2 = 1, CNT_NACC = 2, CNT_N1_ORIG = 3, CNT_N2_ORIG
 struct PairWs {
     uint32_t *rowkey, *colkey, *rows0, *rows1, *cols0, *cols1; // no runtime-indexed arrays: they would live in scratch
     int32_t *mk2, *md;
-    uint32_t *rowbnd, *bndfin; // per row: list bound of the running wide round (atomicMin target) / of the last finished one
     int32_t *cnt;
     uint32_t *skeys;
-    uint8_t *tail;             // the tail's area (128-byte aligned): layout below
+    uint16_t *dcache;
 };
 
 __host__ __device__ inline size_t pow2_ge(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
 
-// Tail area of one image pair (bytes):
-//   256-bit descriptors (k_res_lists -> k_match_gs):
-//     lists  [TAIL_MAX][2][LSUB]  per residual row and lane half: the row's nearest columns as (distance << 13 | column position)
-//     lcnt   [TAIL_MAX][2]        entries per sub-list; above LSUB - LMARGIN: overflowed, the row's list is not used
-//     lcnt2  [TAIL_MAX][16] u8    k_match_gs's later stretches of a row's list: 16 groups of up to 16 entries over the same slots
-//   other lengths: the u16 matrices D and D^T of the LDS tail (<= PGX_TAIL_FILL_MAX^2 each), over the same bytes
-//   free   [2][S]                 gs_fallback's two free lists (any-size path)
-constexpr int LSUB = 128;    // slots per sub-list
-constexpr int LMARGIN = 16;  // a lane appends up to 16 entries between two overflow checks
-constexpr size_t TAIL_LISTS_OFF = 0;
-constexpr size_t TAIL_LCNT_OFF = TAIL_LISTS_OFF + (size_t)PGX_TAIL_MAX * 2 * LSUB * 4;
-constexpr size_t TAIL_GEN_BYTES = (size_t)4 * PGX_TAIL_FILL_MAX * PGX_TAIL_FILL_MAX;
-constexpr size_t TAIL_LCNT2_OFF = TAIL_LCNT_OFF + (size_t)PGX_TAIL_MAX * 2 * 4;   // k_match_gs: u8 [TAIL_MAX][16], entries per group of a stretch
-constexpr size_t TAIL_LIST_BYTES = TAIL_LCNT2_OFF + (size_t)PGX_TAIL_MAX * 16;
-constexpr size_t TAIL_FREE_OFF = ((TAIL_GEN_BYTES > TAIL_LIST_BYTES ? TAIL_GEN_BYTES : TAIL_LIST_BYTES) + 127) & ~(size_t)127;
-__host__ __device__ inline size_t tail_words(int S) { return (TAIL_FREE_OFF + (size_t)8 * S + 128) / 4; }
-
-// per image pair: 10 arrays of S words, counters, sort keys, the tail area
+// per image pair: 8 arrays of S words, counters, sort keys, and the tail's area:
+//   256-bit descriptors: the residual's u8 distance matrix (R, C <= PGX_TAIL_MAX, rows on 128-byte lines; k_tail_rows_fp4 ->
+//   k_match_gs); other lengths: the u16 matrices D and D^T of the LDS tail (<= PGX_TAIL_FILL_MAX^2 each) over the same bytes;
+//   then gs_fallback's two free lists of S words each (any-size path).
+constexpr size_t TAIL_MAT_BYTES = (size_t)PGX_TAIL_MAX * PGX_TAIL_MAX + 256;
+static_assert((size_t)4 * PGX_TAIL_FILL_MAX * PGX_TAIL_FILL_MAX <= TAIL_MAT_BYTES, "D and D^T of the generic tail share the matrix area");
+__host__ __device__ inline size_t dcache_words(int S) { return TAIL_MAT_BYTES / 4 + (size_t)2 * S; }
 __host__ __device__ inline size_t pair_ws_words(int S)
 {
-    return (size_t)10 * S + CNT_WORDS + pow2_ge((size_t)(S > 1 ? S : 1)) + tail_words(S);
+    return (size_t)8 * S + CNT_WORDS + pow2_ge((size_t)(S > 1 ? S : 1)) + dcache_words(S);
 }
 
 __device__ __forceinline__ PairWs pair_ws(uint32_t *ws, int m, int S)
@@ -79,17 +64,11 @@ __device__ __forceinline__ PairWs pair_ws(uint32_t *ws, int m, int S)
     p.cols0 = b + 4 * (size_t)S; p.cols1 = b + 5 * (size_t)S;
     p.mk2 = reinterpret_cast<int32_t *>(b + 6 * (size_t)S);
     p.md = reinterpret_cast<int32_t *>(b + 7 * (size_t)S);
-    p.rowbnd = b + 8 * (size_t)S; p.bndfin = b + 9 * (size_t)S;
-    p.cnt = reinterpret_cast<int32_t *>(b + 10 * (size_t)S);
-    p.skeys = b + 10 * (size_t)S + CNT_WORDS;
-    uint32_t *t = p.skeys + pow2_ge((size_t)(S > 1 ? S : 1));
-    p.tail = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(t) + 127) & ~(uintptr_t)127);
+    p.cnt = reinterpret_cast<int32_t *>(b + 8 * (size_t)S);
+    p.skeys = b + 8 * (size_t)S + CNT_WORDS;
+    p.dcache = reinterpret_cast<uint16_t *>(p.skeys + pow2_ge((size_t)(S > 1 ? S : 1)));
     return p;
 }
-__device__ __forceinline__ uint32_t *tail_lists(const PairWs &p) { return reinterpret_cast<uint32_t *>(p.tail + TAIL_LISTS_OFF); }
-__device__ __forceinline__ uint32_t *tail_lcnt(const PairWs &p) { return reinterpret_cast<uint32_t *>(p.tail + TAIL_LCNT_OFF); }
-__device__ __forceinline__ uint32_t *tail_lcnt2(const PairWs &p) { return reinterpret_cast<uint32_t *>(p.tail + TAIL_LCNT2_OFF); }
-__device__ __forceinline__ uint32_t *tail_free(const PairWs &p) { return reinterpret_cast<uint32_t *>(p.tail + TAIL_FREE_OFF); }
 
 __global__ __launch_bounds__(256) void k_match_init(uint32_t *ws, const int32_t *__restrict__ counts,
                                                     const int32_t *__restrict__ pairlist, int S, int max_n,
@@ -107,8 +86,6 @@ __global__ __launch_bounds__(256) void k_match_init(uint32_t *ws, const int32_t 
         p.cols0[i] = (uint32_t)i;
         p.mk2[i] = -1;
         p.md[i] = PGX_DIST_NONE;
-        p.rowbnd[i] = PGX_KEY_NONE;
-        p.bndfin[i] = PGX_KEY_NONE;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         p.cnt[CNT_N1] = n1; p.cnt[CNT_N2] = n2; p.cnt[CNT_NACC] = 0;
@@ -250,7 +227,7 @@ __device__ void select_compact_wg(PairWs p, int parity, uint32_t *wsum)
         uint32_t o = ex;
         for (int r = b; r < e; r++) {
             const uint32_t i = rows[r];
-            if (p.mk2[i] < 0) { nrows[o++] = i; p.rowkey[i] = PGX_KEY_NONE; p.bndfin[i] = p.rowbnd[i]; p.rowbnd[i] = PGX_KEY_NONE; }
+            if (p.mk2[i] < 0) { nrows[o++] = i; p.rowkey[i] = PGX_KEY_NONE; }
         }
         __syncthreads();
         if (tid == 0) { p.cnt[CNT_NACC] += n1 - (int)tot; p.cnt[CNT_N1] = (int)tot; }
@@ -398,8 +375,8 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nth >> 6;
     const int R = p.cnt[CNT_N1], C = p.cnt[CNT_N2];
     const int Cs = (C + 7) & ~7, Rs = (R + 7) & ~7;       // row strides of the two cached matrices (16-B rows)
-    uint16_t *D = reinterpret_cast<uint16_t *>(p.tail);   // D[i][j], i < R, j < Cs
-    uint16_t *DT = D + (size_t)PGX_TAIL_FILL_MAX * PGX_TAIL_FILL_MAX; // DT[j][i]
+    uint16_t *D = p.dcache;                                // D[i][j], i < R, j < Cs
+    uint16_t *DT = p.dcache + (size_t)PGX_TAIL_FILL_MAX * PGX_TAIL_FILL_MAX; // DT[j][i]
     uint32_t *rl = lds, *cl = rl + TAIL_MAX, *rbest = cl + TAIL_MAX, *cbest = rbest + TAIL_MAX;
     uint32_t *rdl = cbest + TAIL_MAX, *cdl = rdl + TAIL_MAX;
     uint8_t *ralive = reinterpret_cast<uint8_t *>(cdl + TAIL_MAX), *calive = ralive + TAIL_MAX;
@@ -624,8 +601,18 @@ __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uin
 
 } // namespace
 
-#include "k_match_mfma.inc"
+// The residual byte matrix of an image pair (k_tail_rows* write it, k_match_gs reads it): rows start on 128-byte lines.
+// The rows kernel is bound by its HBM writes, and a store instruction of it covers 16 rows x 64 bytes: with rows on line
+// boundaries the two halves of a line come from neighbouring wavefronts of one workgroup and leave L2 as whole lines
+// (tools/probe/write_pattern.hip: 120 -> 96 us for 385 MB in that pattern).
+__device__ __forceinline__ int tail_row_stride(int C) { return (C + 127) & ~127; }
+__device__ __forceinline__ uint8_t *tail_matrix(const PairWs &p)
+{
+    return reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(p.dcache) + 127) & ~(uintptr_t)127);
+}
+
 #include "k_match_tail.inc"
+#include "k_match_mfma.inc"
 
 size_t pgx_match_ws_bytes(int M, int stride) { return (size_t)M * pair_ws_words(stride) * 4; }
 
@@ -672,18 +659,15 @@ void pgx_launch_match_wide(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, 
                            dim3(256), 0, s, ws, d_counts, d_pairlist, plan.stride, plan.max_n, status);
     }
     for (int r = 0; r < plan.rounds_mfma; r++) {
-        // 256-bit descriptors: the first round runs for every image pair whatever its size -- besides the mutual-nearest
-        // edges it yields every row's list bound (k_ham_fp4), without which the tail has no tier-1 lists
-        const int skip = (plan.words == 8 && r == 0) ? 0 : plan.skip_below;
         {
             ProfScope ps(ctx, "ham_argmin", s);
-            if (plan.words == 8) pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan, skip);   // 256-bit descriptors: the matrix pipe
-            else launch_rounds_valu<0>(s, ws, d_desc, d_pairlist, plan);                      // any other length: xor + popcount
+            if (plan.words == 8) pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan);   // 256-bit descriptors: the matrix pipe
+            else launch_rounds_valu<0>(s, ws, d_desc, d_pairlist, plan);                // any other length: xor + popcount
         }
         {
             ProfScope ps(ctx, "match_select", s);
             hipLaunchKernelGGL(k_match_select, dim3(plan.M), dim3(SEL_NT), 0, s, ws, plan.stride,
-                               reinterpret_cast<unsigned long long *>(status + 4) + (r < PGX_MAX_WIDE_ROUNDS ? r : PGX_MAX_WIDE_ROUNDS - 1), skip);
+                               reinterpret_cast<unsigned long long *>(status + 4) + (r < PGX_MAX_WIDE_ROUNDS ? r : PGX_MAX_WIDE_ROUNDS - 1), plan.skip_below);
         }
     }
 }
@@ -694,7 +678,7 @@ void pgx_launch_match_rows(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, 
     if (plan.M <= 0 || plan.words != 8) return;
     uint32_t *ws = reinterpret_cast<uint32_t *>(wsv);
     ProfScope ps(ctx, "tail_rows", s);
-    hipLaunchKernelGGL(k_res_lists, dim3(PGX_TAIL_MAX / RL_ROWS, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
+    hipLaunchKernelGGL(k_tail_rows_fp4, dim3(PGX_TAIL_MAX / TM_ROWS, plan.M), dim3(256), 0, s, ws, d_desc, d_pairlist, plan.stride);
 }
 
 void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_pairlist,
@@ -706,20 +690,7 @@ void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc
     if (plan.words == 8) {
         const size_t n2p = pow2_ge((size_t)(plan.max_n > 1 ? plan.max_n : 1));
         const size_t key_cap = n2p <= 8192 ? n2p : 0; // sort keys in LDS up to 32 KiB, else in the workspace
-        const size_t dyn = (key_cap > (size_t)2 * PGX_TAIL_MAX ? key_cap : (size_t)2 * PGX_TAIL_MAX) * 4; // the residual's column and row indices during the matching, then sort keys
-        static bool attr_set = false;
-        if (!attr_set) { // static + dynamic LDS may exceed 64 KiB
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_gs), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            attr_set = true;
-            if (getenv("PGX_DEBUG_OCC")) {
-                int nb = -1;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_match_gs), GS_NT, dyn);
-                hipFuncAttributes fa;
-                (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_match_gs));
-                fprintf(stderr, "k_match_gs: %d blocks/CU at dyn %zu; static LDS %zu regs %d scratch %zu\n", nb, dyn, fa.sharedSizeBytes, fa.numRegs, fa.localSizeBytes);
-            }
-        }
-        hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(GS_NT), dyn, s, ws, d_desc, d_pairlist, plan.stride, d_out,
+        hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(GS_NT), key_cap * 4, s, ws, d_desc, d_pairlist, plan.stride, d_out,
                            (uint32_t)key_cap, status);
     } else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out, status);
 }

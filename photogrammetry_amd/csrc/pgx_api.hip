@@ -160,7 +160,6 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     plan.skip_below = words == 8 ? PGX_TAIL_MAX : PGX_TAIL_FILL_MAX;
     for (int n = plan.max_n; n > plan.skip_below && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
     if (plan.rounds_mfma > 0 && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS) plan.rounds_mfma++;
-    if (words == 8 && plan.rounds_mfma == 0) plan.rounds_mfma = 1; // small sets too: the round that yields the tail's list bounds
     HIPCHK(c, hipMemsetAsync(c->d_status + 4, 0, PGX_MAX_WIDE_ROUNDS * 8, c->stream));
     if (M <= CHUNK || c->prof_serial) { // everything in order on the context's stream
         for (int m0 = 0; m0 < M; m0 += CHUNK) {
@@ -284,6 +283,8 @@ void pgx_ctx_destroy(pgx_ctx *c)
                       &c->ws_rawscore, &c->ws_nms, &c->ws_order, &c->ws_nkept, &c->st_a, &c->st_b, &c->st_c,
                       &c->st_d, &c->st_e, &c->st_f, &c->ws_pose, &c->ws_matchn[0], &c->ws_matchn[1], &c->ws_matchn[2], &c->ws_matchn[3]};
     for (DevBuf *b : bufs) b->release();
+    c->pin_in.release();
+    c->pin_out.release();
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (int k = 0; k < 4; k++) {
@@ -559,6 +560,63 @@ int pgx_match(pgx_ctx *c, const uint32_t *desc1, int n1, const uint32_t *desc2, 
     if (rc != PGX_OK) return rc;
     HIPCHK(c, hipMemcpyAsync(out, c->st_c.p, (size_t)n1 * sizeof(pgx_pair), hipMemcpyDeviceToHost, c->stream));
     return sync_status(c);
+}
+
+int pgx_match_batch(pgx_ctx *c, const uint32_t *const *descs, const int32_t *counts, int n_frames, int words,
+                    const int32_t *pair_list, int n_pairs, pgx_pair *out, int64_t *out_offsets)
+{
+    if (!c || n_frames < 0 || n_pairs < 0 || (n_frames > 0 && (!descs || !counts)) || (n_pairs > 0 && !pair_list))
+        return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    if (words <= 0 || words > 127) return fail(c, PGX_E_BADARG, "words must be in [1, 127]");
+    int S = 1;
+    for (int f = 0; f < n_frames; f++) {
+        if (counts[f] < 0 || counts[f] > (1 << PGX_IDX_BITS)) return fail(c, PGX_E_BADARG, "counts[%d] = %d", f, counts[f]);
+        if (counts[f] > 0 && !descs[f]) return fail(c, PGX_E_BADARG, "descs[%d] is null", f);
+        if (counts[f] > S) S = counts[f];
+    }
+    int64_t total = 0;
+    bool empty_set = false;
+    for (int m = 0; m < n_pairs; m++) {
+        const int fa = pair_list[2 * m], fb = pair_list[2 * m + 1];
+        if (fa < 0 || fa >= n_frames || fb < 0 || fb >= n_frames) return fail(c, PGX_E_BADARG, "pair %d names frame %d / %d of %d", m, fa, fb, n_frames);
+        if (out_offsets) out_offsets[m] = total;
+        total += counts[fa];
+        if (counts[fa] > 0 && counts[fb] == 0) empty_set = true;
+    }
+    if (out_offsets) out_offsets[n_pairs] = total;
+    if (n_pairs == 0 || total == 0) return PGX_OK;
+    if (!out) return fail(c, PGX_E_BADARG, "null pointer");
+    // stage: [F][S][words] descriptors + counts + pair list in one pinned block, one upload
+    const size_t desc_bytes = (size_t)n_frames * S * words * 4, cnt_bytes = ((size_t)n_frames * 4 + 15) & ~(size_t)15;
+    const size_t pl_bytes = (size_t)n_pairs * 8, in_bytes = desc_bytes + cnt_bytes + pl_bytes;
+    const size_t out_bytes = (size_t)n_pairs * S * sizeof(pgx_pair);
+    HIPCHK(c, c->pin_in.ensure(in_bytes));
+    HIPCHK(c, c->pin_out.ensure(out_bytes));
+    HIPCHK(c, c->st_a.ensure(in_bytes));
+    HIPCHK(c, c->st_c.ensure(out_bytes));
+    uint8_t *hin = c->pin_in.as<uint8_t>();
+    for (int f = 0; f < n_frames; f++)
+        if (counts[f] > 0) memcpy(hin + (size_t)f * S * words * 4, descs[f], (size_t)counts[f] * words * 4);
+    memcpy(hin + desc_bytes, counts, (size_t)n_frames * 4);
+    memcpy(hin + desc_bytes + cnt_bytes, pair_list, pl_bytes);
+    HIPCHK(c, hipMemcpyAsync(c->st_a.p, hin, in_bytes, hipMemcpyHostToDevice, c->stream));
+    uint8_t *din = c->st_a.as<uint8_t>();
+    int rc = enqueue_match(c, reinterpret_cast<const uint32_t *>(din), reinterpret_cast<const int32_t *>(din + desc_bytes), S, words,
+                           reinterpret_cast<const int32_t *>(din + desc_bytes + cnt_bytes), n_pairs, S, c->st_c.as<pgx_pair>());
+    if (rc != PGX_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pin_out.p, c->st_c.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    rc = sync_status(c);
+    if (rc != PGX_OK && rc != PGX_E_EMPTY_SET) return rc;
+    const pgx_pair *hout = c->pin_out.as<pgx_pair>();
+    int64_t o = 0;
+    for (int m = 0; m < n_pairs; m++) {
+        const int n = counts[pair_list[2 * m]];
+        if (n > 0) memcpy(out + o, hout + (size_t)m * S, (size_t)n * sizeof(pgx_pair));
+        o += n;
+    }
+    if (empty_set || rc == PGX_E_EMPTY_SET) return fail(c, PGX_E_EMPTY_SET, "keypoints2 is empty while keypoints1 is not (ArgumentOutOfRangeException)");
+    return PGX_OK;
 }
 
 int pgx_detect(pgx_ctx *c, const uint16_t *rgba, int W, int H, pgx_keypoint *kp_out, uint32_t *desc_out,

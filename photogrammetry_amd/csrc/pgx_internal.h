@@ -47,6 +47,23 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// pinned host staging (hipHostMalloc), grown on demand
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     int launches = 0;
@@ -85,6 +102,7 @@ struct pgx_ctx {
     DevBuf ws_gray, ws_seg, ws_segoff, ws_nraw, ws_rawxy, ws_rawscore, ws_nms, ws_order, ws_nkept;
     // host-API staging
     DevBuf st_a, st_b, st_c, st_d, st_e, st_f;
+    PinBuf pin_in, pin_out; // pgx_match_batch
     // match workspaces: four, so that with several chunks of image pairs the stages of consecutive chunks run side by side
     DevBuf ws_matchn[4];
     DevBuf ws_pose;

@@ -56,6 +56,10 @@ int main()
         }
         const std::vector<KeypointPair> pairs = matching.MatchKeypoints(kept[0], kept[1]);
         for (const KeypointPair &p : pairs) std::printf("pair %d %d %d\n", p.Keypoint1, p.Keypoint2, p.Distance);
+        // both directions and a self match in one batched call (pgx_match_batch)
+        const std::vector<std::vector<KeypointPair>> lists = matching.MatchKeypointsBatch({kept[0], kept[1]}, {{0, 1}, {1, 0}, {1, 1}});
+        for (size_t m = 0; m < lists.size(); m++)
+            for (const KeypointPair &p : lists[m]) std::printf("batch %zu %d %d %d\n", m, p.Keypoint1, p.Keypoint2, p.Distance);
 
         // error behaviour of the reference, mapped back to exception types
         int errors = 0;

@@ -217,6 +217,35 @@ class KeypointMatching {
         return res;
     }
 
+    // The same for many image pairs in one call (pgx_match_batch): frames[f] = a keypoint list, pairs = (frame a, frame b).
+    // No reference counterpart (TestService.cs:96 matches one pair); same result per pair as MatchKeypoints.
+    std::vector<std::vector<KeypointPair>> MatchKeypointsBatch(const std::vector<std::vector<Keypoint>> &frames,
+                                                               const std::vector<std::pair<int, int>> &pairs) const
+    {
+        const int F = (int)frames.size(), M = (int)pairs.size();
+        int words = 8;
+        for (const auto &f : frames) if (!f.empty()) { words = (int)f[0].BriefDescriptor.size(); break; }
+        std::vector<std::vector<uint32_t>> packed(F);
+        std::vector<const uint32_t *> ptrs(F ? F : 1, nullptr);
+        std::vector<int32_t> counts(F ? F : 1, 0), pl(2 * (size_t)(M ? M : 1), 0);
+        for (int f = 0; f < F; f++) {
+            counts[f] = (int32_t)frames[f].size();
+            packed[f].resize((size_t)counts[f] * words);
+            for (int i = 0; i < counts[f]; i++)
+                std::copy(frames[f][i].BriefDescriptor.begin(), frames[f][i].BriefDescriptor.end(), packed[f].begin() + (size_t)i * words);
+            ptrs[f] = packed[f].data();
+        }
+        size_t total = 0;
+        for (int m = 0; m < M; m++) { pl[2 * m] = pairs[m].first; pl[2 * m + 1] = pairs[m].second; total += frames[pairs[m].first].size(); }
+        std::vector<pgx_pair> out(total + 1);
+        std::vector<int64_t> offs((size_t)M + 1, 0);
+        ctx_.check(pgx_match_batch(ctx_.get(), ptrs.data(), counts.data(), F, words, pl.data(), M, out.data(), offs.data()));
+        std::vector<std::vector<KeypointPair>> res(M);
+        for (int m = 0; m < M; m++)
+            for (int64_t i = offs[m]; i < offs[m + 1]; i++) res[m].push_back({out[i].k1, out[i].k2, out[i].dist});
+        return res;
+    }
+
   private:
     Context &ctx_;
 };

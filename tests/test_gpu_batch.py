@@ -97,6 +97,30 @@ def test_match_batch_ragged_counts_and_order(engine):
         assert (got[:, 0] == exp["k1"]).all() and (got[:, 1] == exp["k2"]).all() and (got[:, 2] == exp["dist"]).all(), (a, b)
 
 
+def test_match_batch_host_buffers(engine):
+    """pgx_match_batch: many image pairs from HOST arrays in one call (SURVEY 8b "Call sites") -- the same lists as one
+    pgx_match per pair, ragged sizes, an empty first set, and the reference's exception for an empty second set."""
+    rng = np.random.default_rng(11)
+    sizes = [900, 37, 1300, 0, 512]
+    descs = [rng.integers(0, 2**32, (n, 8), dtype=np.uint32) for n in sizes]
+    descs[4] = descs[0][:512].copy()
+    pl = [(0, 2), (2, 0), (1, 4), (4, 0), (3, 1), (1, 1)]
+    lists = engine.match_batch(descs, pl)
+    assert [len(x) for x in lists] == [sizes[a] for a, _ in pl]
+    for (a, b), got in zip(pl, lists):
+        if sizes[a] == 0:
+            continue
+        exp = cref.match_sorted(descs[a], descs[b])
+        assert (got["k1"] == exp["k1"]).all() and (got["k2"] == exp["k2"]).all() and (got["dist"] == exp["dist"]).all(), (a, b)
+        one = engine.match(descs[a], descs[b])
+        assert (one == got).all()
+    with pytest.raises(pg.ArgumentOutOfRangeException):
+        engine.match_batch(descs, [(0, 2), (0, 3)])     # keypoints2 empty, keypoints1 not: KeypointMatching.cs:61
+    got = engine.last_batch_lists                       # every list is still there
+    assert (got[0] == lists[0]).all() and len(got[1]) == sizes[0] and (got[1]["dist"] == cref.INT_MAX).all()
+    assert engine.match_batch(descs, []) == []
+
+
 def test_match_batch_empty_second_set_raises(engine):
     rng = np.random.default_rng(6)
     descs = [rng.integers(0, 2**32, (30, 8), dtype=np.uint32), np.zeros((0, 8), np.uint32)]

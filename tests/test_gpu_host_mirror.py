@@ -51,5 +51,8 @@ def test_host_mirror_matches_oracle():
     assert len(descs[0]) > 8 and len(descs[1]) > 8
     for m in cref.match(descs[0], descs[1]):
         exp.append("pair %d %d %d" % (m["k1"], m["k2"], m["dist"]))
+    for k, (a, b) in enumerate([(0, 1), (1, 0), (1, 1)]):
+        for m in cref.match(descs[a], descs[b]):
+            exp.append("batch %d %d %d %d" % (k, m["k1"], m["k2"], m["dist"]))
     exp.append("exceptions 15")
     assert lines == exp
