@@ -110,7 +110,11 @@ def test_configs4_chain_every_stage_against_its_oracle():
             n = len(p1)
             Fo, co, so = pose_np.ransac_fundamental(p1, p2, N_SAMPLES, PPS, THR, SEED, m=m)
             tol = max(3, n // 100)
-            assert abs(int(cnt[m]) - co) <= tol, (m, cnt[m], co)
+            # the maximum over all samples: comparable only when the samples have clear null vectors.  A list that is mostly
+            # tail entries (680 of 865 here) fills a sample with copies of ONE point pair: its 8-point system is rank
+            # deficient, the null space has several dimensions and the two solvers legitimately pick different vectors.
+            if tail[m] * 20 < n:
+                assert abs(int(cnt[m]) - co) <= tol, (m, cnt[m], co)
             # the GPU's winner: that sample's matrix by the oracle, and that many inliers when the oracle scores the GPU's matrix
             idx = pose_np.sample_indices(SEED, m, int(bs[m]), PPS, n)
             if tail[m]:
@@ -122,7 +126,28 @@ def test_configs4_chain_every_stage_against_its_oracle():
                 assert np.abs(_normed(Fg[m]) - _normed(Fs)).max() < 2e-3, m
                 checked_F += 1
             assert abs(int(pose_np.score(Fg[m].reshape(3, 3), p1, p2, THR).sum()) - int(cnt[m])) <= tol, m
-        assert checked_F >= 3
+        # single samples on the real lists (n_samples = 1: sample 0 of every image pair is the winner by definition), so that
+        # the matrix comparison does not depend on WHICH sample wins
+        d_F1 = torch.zeros((M, 9), dtype=torch.float32, device=DEV)
+        for seed in range(5):
+            with torch.cuda.stream(stream):
+                eng.fundamental_ransac_dev(job.kp_l, job.out_all, job.counts_all, d_pl, M, NKP, 1, PPS, THR, d_F1, d_in, d_bs, seed=seed)
+            eng.check_status()
+            F1, c1 = d_F1.cpu().numpy(), d_in.cpu().numpy()
+            for m in [0, 5, 12, pl.index((7, 0)), pl.index((7, 3))]:
+                p1, p2 = corr[m]
+                idx = pose_np.sample_indices(seed, m, 0, PPS, len(p1))
+                sv = np.linalg.svd(_system(p1[idx], p2[idx]), compute_uv=False)
+                if sv[-2] > 50 * sv[-1] and sv[-2] > 1e-6 * sv[0]:
+                    Fs = pose_np.estimate_fundamental(p1[idx], p2[idx])
+                    co1 = int(pose_np.score(Fs, p1, p2, THR).sum())
+                    if int(c1[m]) < 0:      # no sample with an inlier: bestF stays null (CameraPoseEstimation.cs:79-89), -1 here
+                        assert co1 <= max(3, len(p1) // 100), (seed, m, co1)
+                        continue
+                    assert np.abs(_normed(F1[m]) - _normed(Fs)).max() < 2e-3, (seed, m)
+                    assert abs(co1 - int(c1[m])) <= max(3, len(p1) // 100), (seed, m)
+                    checked_F += 1
+        assert checked_F >= 8
 
         # ---- pose from the GPU's matrices -----------------------------------------------------------------------------------
         d_Rt = torch.zeros((M, 12), dtype=torch.float32, device=DEV)
