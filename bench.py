@@ -55,7 +55,7 @@ SEQ_FRAMES = 64
 MFMA_FP4 = True
 I8_MFMA_PEAK_OPS = 10.0e15   # name kept from round 1: operations of the 256-bit +-1 contraction per second (dense FP4 peak)
 HBM_PEAK = 8.0e12
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 
 
 def log(*a):
