@@ -83,6 +83,10 @@ def parse_args(argv=None):
                     help="jobs kept in flight: consecutive steps alternate between this many contexts (each with its own streams and "
                          "buffers), so one job's detect / exchanges run beside another job's match (measured on one GPU: 12.61 ms per step "
                          "against 12.62 -- the matcher's own chunk pipeline already fills the chip); 1 = strictly one job at a time")
+    ap.add_argument("--c-abi-comm", action="store_true",
+                    help="N > 1: after the timed region, run the same job once more through the C ABI's own RCCL communicator "
+                         "(pgx_comm_init + pgx_sequence_step_dev) and compare.  Off by default: it loads a second RCCL instance next to "
+                         "torch's, has never run at N > 1 (the development box has one GPU), and a crash or hang there would lose the headline line")
     ap.add_argument("--master-port", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -497,7 +501,7 @@ def worker(args):
     # N > 1: the same job once more through the C ABI's own communicator (pgx_comm_init / pgx_sequence_step_dev: what a
     # non-Python host would call) -- results must equal the torch.distributed run; informative, never `value`
     c_abi = None
-    if world > 1 and not rehearse:
+    if world > 1 and not rehearse and args.c_abi_comm:
         try:
             box = [pg.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
