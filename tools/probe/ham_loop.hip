@@ -142,6 +142,113 @@ __global__ __launch_bounds__(256, 2) void loop_indep(const uint32_t *__restrict_
     if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+using i32x4 = int __attribute__((ext_vector_type(4)));
+using i32x16 = int __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int max16i(const i32x16 &v)
+{
+    const int m0 = max(max(v[0], v[1]), v[2]), m1 = max(max(v[3], v[4]), v[5]), m2 = max(max(v[6], v[7]), v[8]);
+    const int m3 = max(max(v[9], v[10]), v[11]), m4 = max(max(v[12], v[13]), v[14]);
+    return max(max(max(m0, m1), max(m2, m3)), max(m4, v[15]));
+}
+// the shipped kernel's loop, source form for source form; SHARE: column fragments expanded once per workgroup through LDS
+template <int RT, bool SHARE>
+__global__ __launch_bounds__(256, 2) void loop_kernel(const uint32_t *__restrict__ desc, int ntile, int *out, long long *cyc)
+{
+    __shared__ uint32_t colidx[4096 + 256];
+    __shared__ int colbest[4096];
+    __shared__ i32x4 bring[2][4][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+    for (int c = tid; c < 4096 + 256; c += blockDim.x) colidx[c] = (uint32_t)((c * 7 + blockIdx.x) & 4095);
+    for (int c = tid; c < 4096; c += blockDim.x) colbest[c] = -(1 << 30);
+    int km = (int)0x88888888, kc = 0x22222222;
+    asm volatile("" : "+v"(km), "+v"(kc));
+    int afr[RT][4][4];
+    for (int t = 0; t < RT; t++) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(desc + (size_t)((tid + 37 * t) & 4095) * 8 + 4 * h);
+        expand_fp4(w.x, km, kc, afr[t][0][0], afr[t][0][1], afr[t][0][2], afr[t][0][3]);
+        expand_fp4(w.y, km, kc, afr[t][1][0], afr[t][1][1], afr[t][1][2], afr[t][1][3]);
+        expand_fp4(w.z, km, kc, afr[t][2][0], afr[t][2][1], afr[t][2][2], afr[t][2][3]);
+        expand_fp4(w.w, km, kc, afr[t][3][0], afr[t][3][1], afr[t][3][2], afr[t][3][3]);
+    }
+    f32x16 cc;
+    int rbest[RT][16];
+    for (int g = 0; g < 16; g++) {
+        cc[g] = (float)((1 << 22) + ((127 << 7) | (127 - g)));
+        for (int t = 0; t < RT; t++) rbest[t][g] = 0;
+    }
+    __syncthreads();
+    auto fetch = [&](int ct) -> uint4 { return *reinterpret_cast<const uint4 *>(desc + (size_t)(colidx[(ct & 127) * 32 + r] & 4095u) * 8 + 4 * h); };
+    const int kwv = (127 - wv) << 7;
+    auto body = [&](int ct, const int (&b)[4][4]) {
+        int cm = 0;
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+            f32x16 acc = cc;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                const i32x8 av = {afr[t][s4][0], afr[t][s4][1], afr[t][s4][2], afr[t][s4][3], 0, 0, 0, 0};
+                const i32x8 bv = {b[s4][0], b[s4][1], b[s4][2], b[s4][3], 0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 4, 4, 0, 140, 0, 127);
+            }
+            i32x16 ai;
+#pragma unroll
+            for (int g = 0; g < 16; g++) ai[g] = __float_as_int(acc[g]);
+#pragma unroll
+            for (int g = 0; g < 16; g++) rbest[t][g] = max(rbest[t][g], ai[g]);
+            cm = max(cm, __float_as_int(__int_as_float(max16i(ai)) - (float)(32 * t)));
+        }
+        const int cmi = (int)__int_as_float(cm) - (1 << 22);
+        atomicMax(&colbest[(ct & 127) * 32 + r], (cmi & (int)0xFFFFC07F) | kwv);
+#pragma unroll
+        for (int g = 0; g < 16; g++) cc[g] -= 128.0f;
+    };
+    const long long t0 = wall_clock64();
+    if (!SHARE) {
+        uint4 w0 = fetch(0), w1 = fetch(1), w2 = fetch(2), w3 = fetch(3);
+        auto step = [&](int ct, uint4 &slot) {
+            int b[4][4];
+            expand_fp4(slot.x, km, kc, b[0][0], b[0][1], b[0][2], b[0][3]);
+            expand_fp4(slot.y, km, kc, b[1][0], b[1][1], b[1][2], b[1][3]);
+            expand_fp4(slot.z, km, kc, b[2][0], b[2][1], b[2][2], b[2][3]);
+            expand_fp4(slot.w, km, kc, b[3][0], b[3][1], b[3][2], b[3][3]);
+            slot = fetch(ct + 4);
+            body(ct, b);
+        };
+        for (int ct = 0; ct + 4 <= ntile; ct += 4) { step(ct, w0); step(ct + 1, w1); step(ct + 2, w2); step(ct + 3, w3); }
+    } else {
+        auto stage = [&](int half, const uint4 &w) {
+            int f[4][4];
+            expand_fp4(w.x, km, kc, f[0][0], f[0][1], f[0][2], f[0][3]);
+            expand_fp4(w.y, km, kc, f[1][0], f[1][1], f[1][2], f[1][3]);
+            expand_fp4(w.z, km, kc, f[2][0], f[2][1], f[2][2], f[2][3]);
+            expand_fp4(w.w, km, kc, f[3][0], f[3][1], f[3][2], f[3][3]);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) { const i32x4 v = {f[s4][0], f[s4][1], f[s4][2], f[s4][3]}; bring[half][wv][s4][lane] = v; }
+        };
+        uint4 wn = fetch(wv);
+        stage(0, wn);
+        wn = fetch(4 + wv);
+        for (int g = 0; g * 4 < ntile; g++) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage((g + 1) & 1, wn);
+            wn = fetch((g + 2) * 4 + wv);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int b[4][4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) { const i32x4 v = bring[g & 1][q][s4][lane]; b[s4][0] = v[0]; b[s4][1] = v[1]; b[s4][2] = v[2]; b[s4][3] = v[3]; }
+                body(g * 4 + q, b);
+            }
+        }
+    }
+    const long long t1 = wall_clock64();
+    int s = 0;
+    for (int t = 0; t < RT; t++) for (int g = 0; g < 16; g++) s += rbest[t][g];
+    out[blockIdx.x * blockDim.x + tid] = s + colbest[tid] + (int)__float_as_int(cc[3]);
+    if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 template <int NCH, bool SCHED>
 __global__ __launch_bounds__(256, 2) void loop_pipe(const uint32_t *__restrict__ desc, int ntile, int *out, long long *cyc)
 {
@@ -253,6 +360,8 @@ int main()
         run("everything, 2 chains", loop<2, true, true, true, true, true>, 2, blocks);
         run("everything, pipelined over tiles, 2 chains", loop_pipe<2, false>, 2, blocks);
         run("everything, pipelined, 2 chains, sched_group_barrier", loop_pipe<2, true>, 2, blocks);
+        run("the shipped loop, source for source (3 row tiles)", loop_kernel<3, false>, 3, blocks);
+        run("the shipped loop + LDS-shared expansion", loop_kernel<3, true>, 3, blocks);
         run("in-place MFMAs + 24 x 3 independent vector ops", loop_indep<3, 24>, 3, blocks);
         run("in-place MFMAs + 28 x 3 independent vector ops", loop_indep<3, 28>, 3, blocks);
         run("in-place MFMAs + 32 x 3 independent vector ops", loop_indep<3, 32>, 3, blocks);
