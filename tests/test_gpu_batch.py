@@ -121,6 +121,19 @@ def test_match_batch_host_buffers(engine):
     assert engine.match_batch(descs, []) == []
 
 
+@pytest.mark.parametrize("words,mask", [(3, 0xFFFFFFFF), (1, 0x1F), (16, 0xFFFFFFFF)])
+def test_match_batch_host_buffers_other_descriptor_lengths(engine, words, mask):
+    """pgx_match_batch away from 256 bits (the matcher's generic path): 96-, 32- (tie-heavy) and 512-bit descriptors."""
+    rng = np.random.default_rng(words)
+    sizes = [300, 41, 520]
+    descs = [rng.integers(0, 2**32, (n, words), dtype=np.uint32) & np.uint32(mask) for n in sizes]
+    pl = [(0, 2), (2, 0), (1, 0), (2, 2)]
+    lists = engine.match_batch(descs, pl)
+    for (a, b), got in zip(pl, lists):
+        exp = cref.match_sorted(descs[a], descs[b])
+        assert (got["k1"] == exp["k1"]).all() and (got["k2"] == exp["k2"]).all() and (got["dist"] == exp["dist"]).all(), (a, b)
+
+
 def test_match_batch_empty_second_set_raises(engine):
     rng = np.random.default_rng(6)
     descs = [rng.integers(0, 2**32, (30, 8), dtype=np.uint32), np.zeros((0, 8), np.uint32)]
