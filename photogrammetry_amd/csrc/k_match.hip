@@ -274,7 +274,7 @@ __global__ __launch_bounds__(SEL_NT) void k_match_select(uint32_t *ws, int S, un
 // threads), so up to three consecutive stages j = 4s, 2s, s of a merge are fused: a thread takes the 8 keys whose indices
 // differ in the bits s, 2s, 4s, runs the three compare-exchange layers in registers and writes them back -- 30 passes
 // over the keys instead of 78.  The direction bit k lies above all three, so the 8 keys of a thread share it.
-__device__ void bitonic_sort_wg(uint32_t *keys, uint32_t n2p)
+__device__ __forceinline__ void bitonic_sort_wg(uint32_t *keys, uint32_t n2p)
 {
     const uint32_t tid = threadIdx.x, nth = blockDim.x;
     auto cx = [](uint32_t &a, uint32_t &b, bool up) {
@@ -325,6 +325,32 @@ __device__ void bitonic_sort_wg(uint32_t *keys, uint32_t n2p)
         }
     }
     __syncthreads();
+}
+
+// The N1 output entries of one image pair: accepted edges sorted by (dist, k1), then the (0,0,int.MaxValue) tail
+// (KeypointMatching.cs:38-66).  Inlined separately for sort keys in LDS and in the workspace: with ONE call on a pointer
+// selected at run time the key accesses are flat_* instructions (LDS reached through the vector memory path); with two
+// call sites each copy knows its address space and the LDS one sorts with ds_* instructions.
+__device__ __forceinline__ void sort_and_emit(uint32_t *keys, uint32_t n2p, const PairWs &p, int n1o, int nacc, pgx_pair *__restrict__ o)
+{
+    const int tid = threadIdx.x, nth = blockDim.x;
+    for (uint32_t i = tid; i < n2p; i += nth) {
+        uint32_t k = PGX_KEY_NONE;
+        if ((int)i < n1o && p.mk2[i] >= 0) k = ((uint32_t)p.md[i] << PGX_IDX_BITS) | i;
+        keys[i] = k;
+    }
+    bitonic_sort_wg(keys, n2p);
+    for (int e = tid; e < n1o; e += nth) {
+        pgx_pair r;
+        if (e < nacc) {
+            const uint32_t k = keys[e];
+            const uint32_t i = k & PGX_IDX_MASK;
+            r.k1 = (int32_t)i; r.k2 = p.mk2[i]; r.dist = (int32_t)(k >> PGX_IDX_BITS);
+        } else {
+            r.k1 = 0; r.k2 = 0; r.dist = PGX_DIST_NONE;
+        }
+        o[e] = r;
+    }
 }
 
 // ---- LDS-resident tail ---------------------------------------------------------------------
@@ -551,7 +577,7 @@ __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uin
 {
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wsum[SEL_NT / 64];
-    const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const int m = blockIdx.x;
     PairWs p = pair_ws(ws, m, S);
     if (p.cnt[CNT_DONE]) return; // finished by k_match_tail
     int parity = p.cnt[CNT_PARITY];
@@ -579,24 +605,8 @@ __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uin
     const int nacc = p.cnt[CNT_NACC];
     pgx_pair *o = out + (size_t)m * S;
     const uint32_t n2p = (uint32_t)pow2_ge((size_t)(n1o > 1 ? n1o : 1));
-    uint32_t *keys = (n2p <= lds_keys_cap) ? lds : p.skeys;
-    for (uint32_t i = tid; i < n2p; i += nth) {
-        uint32_t k = PGX_KEY_NONE;
-        if ((int)i < n1o && p.mk2[i] >= 0) k = ((uint32_t)p.md[i] << PGX_IDX_BITS) | i;
-        keys[i] = k;
-    }
-    bitonic_sort_wg(keys, n2p);
-    for (int e = tid; e < n1o; e += nth) {
-        pgx_pair r;
-        if (e < nacc) {
-            const uint32_t k = keys[e];
-            const uint32_t i = k & PGX_IDX_MASK;
-            r.k1 = (int32_t)i; r.k2 = p.mk2[i]; r.dist = (int32_t)(k >> PGX_IDX_BITS);
-        } else {
-            r.k1 = 0; r.k2 = 0; r.dist = PGX_DIST_NONE;
-        }
-        o[e] = r;
-    }
+    if (n2p <= lds_keys_cap) sort_and_emit(lds, n2p, p, n1o, nacc, o);
+    else sort_and_emit(p.skeys, n2p, p, n1o, nacc, o);
 }
 
 } // namespace
@@ -608,7 +618,10 @@ __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uin
 __device__ __forceinline__ int tail_row_stride(int C) { return (C + 127) & ~127; }
 __device__ __forceinline__ uint8_t *tail_matrix(const PairWs &p)
 {
-    return reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(p.dcache) + 127) & ~(uintptr_t)127);
+    // pointer + offset (not an integer round trip): the result stays a global-memory pointer, so its loads and stores are
+    // global_* instructions rather than flat_* ones (which also count against the LDS wait counter)
+    uint8_t *b = reinterpret_cast<uint8_t *>(p.dcache);
+    return b + ((128 - (reinterpret_cast<uintptr_t>(b) & 127)) & 127);
 }
 
 #include "k_match_tail.inc"
