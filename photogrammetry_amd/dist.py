@@ -184,7 +184,13 @@ class ShardedSequence:
         overlap_exchange (torch path, G > 1): the all-gather of the match lists -- by far the larger exchange, 12 B x nkp
         per image pair -- is issued asynchronously into one of TWO output buffers and awaited one step later, so it runs
         beside the next step's detect and match instead of after this step's; `finish()` awaits the last one and must be
-        called before the lists are read.  `out_all` / `matches()` then refer to the step issued last."""
+        called before the lists are read.  `out_all` / `matches()` then refer to the step issued last.
+        Both exchanges stay on ONE communicator on purpose: collectives of one communicator run in issue order, so the
+        next step's (small) descriptor gather queues behind the previous step's list gather -- at 8 GPUs that is an
+        estimated 0.4 ms of a 8.8 ms step (792 MB of lists at ~310 GB/s bus bandwidth = 2.2 ms against 1.75 ms of
+        detect), nothing at <= 4 GPUs.  A second communicator would remove it, but two RCCL communicators with
+        collectives in flight at once cannot be rehearsed on the one-GPU development box, and a hang costs the whole
+        run."""
         assert comm in ("torch", "pgx")
         self.comm = comm
         self.overlap = bool(overlap_exchange) and comm == "torch"
