@@ -27,6 +27,7 @@
 //   k_match_finish    one workgroup per image pair: remaining rounds in-kernel (LDS tail below PGX_TAIL_FILL_MAX),
 //                     sort (bitonic, LDS), the N1 output entries
 #include "pgx_internal.h"
+#include <hip/hip_ext.h>
 
 namespace {
 
@@ -673,9 +674,13 @@ void pgx_launch_match_wide(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, 
     }
     for (int r = 0; r < plan.rounds_mfma; r++) {
         {
-            ProfScope ps(ctx, "ham_argmin", s);
-            if (plan.words == 8) pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan);   // 256-bit descriptors: the matrix pipe
-            else launch_rounds_valu<0>(s, ws, d_desc, d_pairlist, plan);                // any other length: xor + popcount
+            if (plan.words == 8) {   // 256-bit descriptors: the matrix pipe
+                ProfScope ps(ctx, "ham_argmin", s, true);
+                pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan, ps.a, ps.b);
+            } else {                 // any other length: xor + popcount
+                ProfScope ps(ctx, "ham_argmin", s);
+                launch_rounds_valu<0>(s, ws, d_desc, d_pairlist, plan);
+            }
         }
         {
             ProfScope ps(ctx, "match_select", s);

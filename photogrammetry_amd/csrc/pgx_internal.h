@@ -147,12 +147,17 @@ __device__ __forceinline__ void pgx_xcd_map(int lin, int nblk, int F, int &f, in
 #endif
 
 // RAII event bracket used by the launchers' callers
+// attach = true: the scope records nothing itself; the ONE kernel launched inside it takes the two events with
+// hipExtLaunchKernelGGL, which stamps the dispatch's own begin and end -- no barrier packets between back-to-back kernels
+// (two hipEventRecord per launch of the distance kernel cost 2.4 % of the bench step)
 struct ProfScope {
     pgx_ctx *c;
     ProfEntry *e = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t st;
-    ProfScope(pgx_ctx *ctx, const char *name, hipStream_t s = nullptr) : c(ctx), st(s ? s : ctx->stream)
+    bool attach;
+    ProfScope(pgx_ctx *ctx, const char *name, hipStream_t s = nullptr, bool attach_to_kernel = false)
+        : c(ctx), st(s ? s : ctx->stream), attach(attach_to_kernel)
     {
         if (!c->prof_on || (!c->prof_only.empty() && c->prof_only != name)) return;
         e = &c->prof[name];
@@ -160,13 +165,13 @@ struct ProfScope {
             if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); return true; }
             return hipEventCreate(&ev) == hipSuccess;
         };
-        if (!take(a) || !take(b)) { e = nullptr; return; }
-        (void)hipEventRecord(a, st);
+        if (!take(a) || !take(b)) { e = nullptr; a = b = nullptr; return; }
+        if (!attach) (void)hipEventRecord(a, st);
     }
     ~ProfScope()
     {
         if (!e) return;
-        (void)hipEventRecord(b, st);
+        if (!attach) (void)hipEventRecord(b, st);
         e->pending.emplace_back(a, b);
     }
 };
