@@ -76,6 +76,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-dewarp", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs / host_api objects (N = 1)")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
+    ap.add_argument("--no-standalone-pass", action="store_true",
+                    help="skip the untimed pass that times every kernel with the matcher stages in order (under rocprofv3 --stats: "
+                         "every launch the profiler sees then ran in the pipelined mode the timed region measures)")
     ap.add_argument("--no-overlap-exchange", action="store_true",
                     help="N > 1: run the all-gather of the match lists synchronously at the end of every step (default: it is issued "
                          "asynchronously and awaited one step later, double-buffered; the last one is awaited inside the timed region)")
@@ -478,7 +481,7 @@ def worker(args):
     # stand-alone kernel times: in the timed region three matcher stages of consecutive chunks share the chip, so their
     # event brackets overlap and stretch each other; a second, untimed pass runs the same steps with the stages in order
     kern_alone, k_alone = {}, max(3, min(20, args.steps))
-    if not args.no_profile:
+    if not args.no_profile and not args.no_standalone_pass:
         eng.profile_reset()
         eng.profile_serialize(True)
         eng.profile_enable(True)
