@@ -158,11 +158,12 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     // 256-bit descriptors: k_tail_rows caches the residual's distance rows up to PGX_TAIL_MAX, so wide rounds stop there;
     // other lengths: the tail workgroup stages the descriptors itself (PGX_TAIL_FILL_MAX)
     plan.skip_below = words == 8 ? PGX_TAIL_MAX : PGX_TAIL_FILL_MAX;
-    // Few image pairs (one pgx_match call, a small batch): the per-pair finish is one workgroup per pair and leaves the chip
-    // idle, so the whole-chip rounds go on to half that size first (N = 4096 random: 0.33 -> 0.26 ms per pgx_match call,
-    // 8 pairs per call 0.085 -> 0.065 ms per pair, 64 pairs 0.034 -> 0.031).  Full chunks keep the hand-off at PGX_TAIL_MAX:
-    // there every CU has a finish workgroup to run and further whole-chip rounds cost more than they save (+0.6 ms per step).
-    if (words == 8 && M <= 64) plan.skip_below = PGX_TAIL_MAX / 2;
+    // One or two image pairs (a pgx_match call): the per-pair finish is one workgroup per pair and leaves the chip idle, so the
+    // whole-chip rounds go on to half that size first.  Measured at N = 4096 (tools/call_latency.py): random descriptor sets
+    // 0.33 -> 0.27 ms per call, detect-chain sets of translated frames 0.29 -> 0.30 (their finish is bound by the number of
+    // its rounds, not by the residual's size), true-match sets unchanged.  From 8 pairs per call on the lower threshold costs
+    // more than it saves on the frame sets (+6 %), and at full chunks +0.6 ms per bench step: those keep PGX_TAIL_MAX.
+    if (words == 8 && M <= 2) plan.skip_below = PGX_TAIL_MAX / 2;
     for (int n = plan.max_n; n > plan.skip_below && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
     if (plan.rounds_mfma > 0 && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS) plan.rounds_mfma++;
     HIPCHK(c, hipMemsetAsync(c->d_status + 4, 0, PGX_MAX_WIDE_ROUNDS * 8, c->stream));
