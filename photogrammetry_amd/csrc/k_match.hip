@@ -676,7 +676,7 @@ void pgx_launch_match_wide(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, 
         {
             if (plan.words == 8) {   // 256-bit descriptors: the matrix pipe
                 ProfScope ps(ctx, "ham_argmin", s, true);
-                pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan, ps.a, ps.b);
+                pgx_launch_ham_mfma(s, ws, d_desc, d_pairlist, plan, ps.a, ps.b, status);
             } else {                 // any other length: xor + popcount
                 ProfScope ps(ctx, "ham_argmin", s);
                 launch_rounds_valu<0>(s, ws, d_desc, d_pairlist, plan);
@@ -707,8 +707,8 @@ void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc
     ProfScope ps(ctx, "match_finish", s);
     if (plan.words == 8) {
         const size_t n2p = pow2_ge((size_t)(plan.max_n > 1 ? plan.max_n : 1));
-        const size_t key_cap = n2p <= 8192 ? n2p : 0; // sort keys in LDS up to 32 KiB, else in the workspace
-        hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(GS_NT), key_cap * 4, s, ws, d_desc, d_pairlist, plan.stride, d_out,
+        const size_t key_cap = n2p <= (size_t)4 * PGX_TAIL_MAX ? n2p : 0; // sort keys over the finish's own LDS state (32 KiB), else in the workspace
+        hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(GS_NT), 0, s, ws, d_desc, d_pairlist, plan.stride, d_out,
                            (uint32_t)key_cap, status);
     } else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out, status);
 }

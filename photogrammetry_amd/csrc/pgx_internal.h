@@ -89,9 +89,10 @@ struct pgx_ctx {
     DevBuf d_map;
     int raw_cap = 1 << 17;
     int kp_cap = 1 << PGX_IDX_BITS; // soft survivor limit of the fused path (pgx_set_capacity); default: none
-    // image pairs per matcher workspace chunk (pgx_set_match_chunk).  128 left three quarters of the chip idle during a
-    // chunk's per-pair finish (one workgroup per pair, two per CU): stand-alone finish 6.2 ms per 2016 pairs; 256: 3.7 ms
-    int match_chunk = 256;
+    // image pairs per matcher workspace chunk (pgx_set_match_chunk).  The per-pair finish is one workgroup per image pair: 128
+    // left three quarters of the chip idle during a chunk's finish; with 512 two finish workgroups share a CU and fill each
+    // other's waits (stand-alone finish of the bench job's 2016 pairs: 2.15 ms at 256, 1.70 at 512; step 8.22 -> 8.09 ms)
+    int match_chunk = 512;
     int src8 = 0; // pgx_set_source_format: 1 = the rgba arguments are 8-bit RGBA
 
     // status words: [0] sticky error bits

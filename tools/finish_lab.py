@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--check", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--no-serial", action="store_true", help="pipelined timing only (for a kernel trace)")
     ap.add_argument("--random", type=int, default=0, help="instead of the sequence: this many image pairs of random 4096-point sets")
     args = ap.parse_args()
     F, W, H, NKP = args.frames, 1920, 1080, args.nkp
@@ -90,18 +91,24 @@ def main():
     eng.check_status()
     out = d_out.cpu().numpy()
     digest = hashlib.sha256(out.tobytes()).hexdigest()[:16]
+    if args.no_serial:
+        print(json.dumps({"tag": args.tag, "pairs": M, "chunk": args.chunk or 256, "ms_pipelined": round(ms_pipe, 4), "sha": digest}), flush=True)
+        eng.close()
+        return
     # stage by stage
     eng.profile_serialize(True)
     eng.profile_reset()
     eng.profile_enable(True)
     match()
     torch.cuda.synchronize()
+    eng.debug_counters()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         match()
     torch.cuda.synchronize()
     ms_serial = (time.perf_counter() - t0) * 1e3 / args.steps
     eng.profile_enable(False)
+    dbg_serial = [x / float(args.steps * M) for x in eng.debug_counters()]
     kern = {}
     for name in ("match_init", "ham_argmin", "match_select", "tail_rows", "match_finish"):
         n, t = eng.profile_get(name)
@@ -112,7 +119,7 @@ def main():
     digest2 = hashlib.sha256(d_out.cpu().numpy().tobytes()).hexdigest()[:16]
     res = {"tag": args.tag, "lib": os.path.basename(os.environ.get("PGX_LIB", "libpgx.so")), "pairs": M, "chunk": args.chunk or 256,
            "ms_pipelined": round(ms_pipe, 4), "ms_serial": round(ms_serial, 4), "kernels_ms": kern, "sha": digest, "sha_serial": digest2,
-           "dbg_per_pair": [round(x, 2) for x in dbg]}
+           "dbg_per_pair": [round(x, 2) for x in dbg], "dbg_per_pair_serial": [round(x, 2) for x in dbg_serial]}
     if args.check:
         from oracle import cref
         desc = d_desc.cpu().numpy().view(np.uint32)
