@@ -504,6 +504,21 @@ __device__ __forceinline__ uint32_t run_pos(const Runs &R, uint32_t fi)
 
 constexpr int NB_REG = 2; // neighbour records per lane and pass (128 neighbours)
 
+// A lane's neighbour record in the champion and push rounds.  EVERY lane loads (lanes past the end of the block re-read its
+// first record and get a state that takes no part in anything), and the callers evaluate what they loaded with bitwise
+// arithmetic instead of short-circuit conditions: no load of mutable state under a per-lane exec mask and no divergent
+// branch between such a load and its use -- the two ingredients of the predicated-load hazard of the mask rounds (DESIGN.md
+// section 4), which these rounds share the third one with (other workgroups' state stores in flight).
+// tests/test_nms_codegen.py checks the generated code for exactly that.
+__device__ __forceinline__ uint4 load_rec_all_lanes(const uint4 *rec, const Runs &R, uint32_t fi, uint32_t &q)
+{
+    const bool in = fi < R.total;
+    q = run_pos(R, in ? fi : 0u);
+    uint4 v = rec[q];
+    v.w = in ? v.w : (uint32_t)ST_SUPPRESSED;
+    return v;
+}
+
 __device__ __forceinline__ unsigned long long sort_key(int score, uint32_t idx)
 {
     const uint32_t inv = ~((uint32_t)score ^ 0x80000000u); // larger score -> smaller key
@@ -531,8 +546,9 @@ __global__ __launch_bounds__(256) void k_nms_phase_a(NmsLayout L, int radius, in
     for (uint32_t pb = p0; pb < p1; pb += 64) { // the cell's own points, 64 at a time
         const uint32_t p = pb + lane;
         const bool have = p < p1;
-        const uint4 me = have ? P.rec[p] : make_uint4(0, 0, 0, ST_SUPPRESSED);
-        const bool und = have && me.w == ST_UNDECIDED;
+        uint4 me = P.rec[have ? p : p0]; // every lane loads (see load_rec_all_lanes)
+        me.w = have ? me.w : (uint32_t)ST_SUPPRESSED;
+        const bool und = me.w == ST_UNDECIDED;
         unsigned long long alive = __ballot(und);
         if (!alive) continue;
         und_seen += (uint32_t)__popcll(alive);
@@ -556,26 +572,23 @@ __global__ __launch_bounds__(256) void k_nms_phase_a(NmsLayout L, int radius, in
             uint4 nb[NB_REG];
             uint32_t nq[NB_REG];
 #pragma unroll
-            for (int k = 0; k < NB_REG; k++) {
-                const uint32_t fi = nb0 + k * 64 + lane;
-                nq[k] = fi < R.total ? run_pos(R, fi) : 0xFFFFFFFFu;
-                nb[k] = fi < R.total ? P.rec[nq[k]] : make_uint4(0, 0, 0, ST_SUPPRESSED);
-            }
+            for (int k = 0; k < NB_REG; k++) nb[k] = load_rec_all_lanes(P.rec, R, nb0 + k * 64 + lane, nq[k]);
             const int nch = (int)(((R.total - nb0 < (uint32_t)(64 * NB_REG) ? R.total - nb0 : (uint32_t)(64 * NB_REG)) + 63) / 64);
             unsigned long long todo = alive;
             while (todo) {
                 const int k = __builtin_ctzll(todo);
                 todo &= todo - 1;
                 const uint4 ce = c_rec[wv][k];
-                bool h = false;
+                uint32_t h = 0;
 #pragma unroll
                 for (int j = 0; j < NB_REG; j++) {
                     if (j >= nch) break; // uniform
                     // a point accepted earlier in THIS phase (NEW) was undecided when the round began
-                    h = h || ((nb[j].w == ST_UNDECIDED || nb[j].w == ST_NEW) && nq[j] != pb + (uint32_t)k &&
-                              within(nb[j].x, ce.x, r2) && better((int)nb[j].y, nb[j].z, (int)ce.y, ce.z));
+                    const uint32_t bet = (uint32_t)((int)nb[j].y > (int)ce.y) | ((uint32_t)((int)nb[j].y == (int)ce.y) & (uint32_t)(nb[j].z < ce.z));
+                    h |= ((uint32_t)(nb[j].w == ST_UNDECIDED) | (uint32_t)(nb[j].w == ST_NEW)) & (uint32_t)(nq[j] != pb + (uint32_t)k) &
+                         (uint32_t)within(nb[j].x, ce.x, r2) & bet;
                 }
-                if (__any(h)) alive &= ~(1ull << k);
+                if (__any(h != 0)) alive &= ~(1ull << k);
             }
         }
         if (alive) { // nobody better within r: accept, and queue for this round's suppression pass
@@ -689,39 +702,35 @@ __device__ __forceinline__ void phase_c_wave(const NmsPtrs &P, const NmsLayout &
         const int kx = __shfl(cx, k), ky = __shfl(cy, k);
         const Runs R = cell_runs_from(cs, cs_bias, L, kx, ky);
         if ((deep >> k) & 1ull) {
-            bool h = false;
+            uint32_t h = 0;
             for (uint32_t nb0 = 0; nb0 < R.total; nb0 += 64 * NB_REG) {
                 uint4 nb[NB_REG];
+                uint32_t nq[NB_REG];
 #pragma unroll
-                for (int j = 0; j < NB_REG; j++) {
-                    const uint32_t fi = nb0 + j * 64 + lane;
-                    nb[j] = fi < R.total ? P.rec[run_pos(R, fi)] : make_uint4(0, 0, 0, ST_SUPPRESSED);
-                }
+                for (int j = 0; j < NB_REG; j++) nb[j] = load_rec_all_lanes(P.rec, R, nb0 + j * 64 + lane, nq[j]);
 #pragma unroll
                 for (int j = 0; j < NB_REG; j++) {
                     // a point accepted earlier in THIS phase (stamped with this round) was undecided when the
                     // round began; the centre itself has key == ckey and drops out of the strict comparison
-                    h = h || ((nb[j].w == ST_UNDECIDED || nb[j].w == ST_ACC_ROUND + (uint32_t)round) &&
-                              champ_key(nb[j].y, nb[j].z) > ckey && within_near(nb[j].x, cxy, r2));
+                    h |= ((uint32_t)(nb[j].w == ST_UNDECIDED) | (uint32_t)(nb[j].w == ST_ACC_ROUND + (uint32_t)round)) &
+                         (uint32_t)(champ_key(nb[j].y, nb[j].z) > ckey) & (uint32_t)within_near(nb[j].x, cxy, r2);
                 }
-                if (__any(h)) break;
+                if (__any(h != 0)) break;
             }
-            if (__any(h)) continue; // beaten: stays undecided
+            if (__any(h != 0)) continue; // beaten: stays undecided
         }
         acc |= 1ull << k;
         for (uint32_t nb0 = 0; nb0 < R.total; nb0 += 64 * NB_REG) {
             uint4 nb[NB_REG];
             uint32_t nq[NB_REG];
 #pragma unroll
-            for (int j = 0; j < NB_REG; j++) {
-                const uint32_t fi = nb0 + j * 64 + lane;
-                nq[j] = fi < R.total ? run_pos(R, fi) : 0u;
-                nb[j] = fi < R.total ? P.rec[nq[j]] : make_uint4(0, 0, 0, ST_SUPPRESSED);
-            }
+            for (int j = 0; j < NB_REG; j++) nb[j] = load_rec_all_lanes(P.rec, R, nb0 + j * 64 + lane, nq[j]);
 #pragma unroll
-            for (int j = 0; j < NB_REG; j++) // the centre itself: key == ckey, skipped
-                if (nb[j].w == ST_UNDECIDED && champ_key(nb[j].y, nb[j].z) != ckey && within_near(nb[j].x, cxy, r2))
-                    *rec_state(P.rec, nq[j]) = ST_SUPPRESSED;
+            for (int j = 0; j < NB_REG; j++) { // the centre itself: key == ckey, skipped
+                const uint32_t kill = (uint32_t)(nb[j].w == ST_UNDECIDED) & (uint32_t)(champ_key(nb[j].y, nb[j].z) != ckey) &
+                                      (uint32_t)within_near(nb[j].x, cxy, r2);
+                if (kill) *rec_state(P.rec, nq[j]) = ST_SUPPRESSED;
+            }
         }
     }
 
@@ -792,14 +801,12 @@ __global__ __launch_bounds__(256) void k_nms_push(NmsLayout L, int radius, int r
             uint4 nb[NB_REG];
             uint32_t nq[NB_REG];
 #pragma unroll
-            for (int k = 0; k < NB_REG; k++) {
-                const uint32_t fi = nb0 + k * 64 + lane;
-                nq[k] = fi < R.total ? run_pos(R, fi) : 0xFFFFFFFFu;
-                nb[k] = fi < R.total ? P.rec[nq[k]] : make_uint4(0, 0, 0, ST_SUPPRESSED);
-            }
+            for (int k = 0; k < NB_REG; k++) nb[k] = load_rec_all_lanes(P.rec, R, nb0 + k * 64 + lane, nq[k]);
 #pragma unroll
-            for (int k = 0; k < NB_REG; k++)
-                if (nb[k].w == ST_UNDECIDED && within(nb[k].x, me.x, r2)) *rec_state(P.rec, nq[k]) = ST_SUPPRESSED;
+            for (int k = 0; k < NB_REG; k++) {
+                const uint32_t kill = (uint32_t)(nb[k].w == ST_UNDECIDED) & (uint32_t)within(nb[k].x, me.x, r2);
+                if (kill) *rec_state(P.rec, nq[k]) = ST_SUPPRESSED;
+            }
         }
         if (lane == 0) {
             *rec_state(P.rec, p) = ST_ACCEPTED;

@@ -12,7 +12,15 @@ What this test pins, on the code object inside libpgx.so itself (llvm-objdump -d
   * k_nmsm_round<2> and <3> have a workgroup barrier, at least one `sc1` load before it, and NO `sc1` load after it;
   * the committed listing of the failing form is flagged by the same check (the checker sees what it is meant to see).
 A compiler upgrade or a refactor that brings mutable-state loads back into the evaluation step turns this red on the CPU,
-before any GPU run.  photogrammetry_amd/csrc/Makefile additionally refuses a hipcc other than the one this was verified with."""
+before any GPU run.  photogrammetry_amd/csrc/Makefile additionally refuses a hipcc other than the one this was verified with.
+
+The record-based rounds (every radius outside 10..21, i.e. the reference's shipped r = 50: k_nms_phase_c<*>, and the general
+path's k_nms_phase_a / k_nms_push) read 16-byte hit records whose state word other workgroups overwrite in the same launch.
+Up to round 3 they did so under a per-lane predicate (`fi < total ? rec[...] : ...`) and evaluated the record with short-circuit
+conditions, i.e. nested exec-masked regions between the load and its use -- the failing shape's ingredients.  Since round 4 every
+lane loads (load_rec_all_lanes) and the evaluation is bitwise; the second group of tests pins that on the code object: after a
+record load (global_load_dwordx4) nothing touches the exec mask until the wave-uniform decision, except the guard of the
+suppression store itself.  The round-3 listing of k_nms_phase_c<2, false> is kept as the checker's positive control."""
 import os
 import re
 import shutil
@@ -40,6 +48,57 @@ def mutable_loads_confined_to_staging(lines):
     if late:
         return False, "%d sc1 load(s) after the first barrier, first at instruction %d: %s" % (len(late), late[0], ins[late[0]].strip())
     return True, "%d sc1 loads, all before the first of %d barriers" % (len(sc1), len(bar))
+
+
+# a hit record is 16 bytes, its state word the last one: whole-record loads, or (where only position and state are used) the
+# load of the state word
+REC_LOAD = re.compile(r"\bglobal_load_dwordx4\b|\bglobal_load_dword\b.*\boffset:12\b")
+
+
+def _instructions(lines):
+    ins = [re.sub(r"//.*$", "", ln).strip() for ln in lines]
+    return [ln for ln in ins if ln and not ln.endswith(":")]
+
+
+def record_load_windows(ins):
+    """[(index of the load, instructions behind its s_waitcnt up to the next wave-uniform decision)] for every record load."""
+    out, k, n = [], 0, len(ins)
+    while k < n:
+        if not REC_LOAD.search(ins[k]):
+            k += 1
+            continue
+        j = k
+        while j + 1 < n and j + 1 - k < 80 and not re.match(r"s_waitcnt\b.*vmcnt", ins[j + 1]) and not re.match(r"s_cbranch|s_branch", ins[j + 1]):
+            j += 1
+        w, t = [], j + 1
+        while t < n:
+            ln = ins[t]
+            if REC_LOAD.search(ln) or re.match(r"s_cbranch_(scc|vcc)|s_branch|s_endpgm|s_andn2_b64\s+exec", ln):
+                break
+            w.append(ln)
+            t += 1
+        out.append((k, w))
+        k = t
+    return out
+
+
+def exec_ops_between_load_and_use(window):
+    """exec-mask instructions of a window that are not the guard of a store (s_and_saveexec, [s_cbranch_execz], global_store)."""
+    bad, i = [], 0
+    while i < len(window):
+        ln = window[i]
+        if re.match(r"s_(and|or|andn2|xor)_saveexec_b64", ln):
+            j = i + 1
+            if j < len(window) and re.match(r"s_cbranch_execz", window[j]):
+                j += 1
+            if j < len(window) and re.match(r"global_store_dword\b", window[j]):
+                i = j + 1
+                continue
+            bad.append(ln)
+        elif re.match(r"s_cbranch_exec", ln):
+            bad.append(ln)
+        i += 1
+    return bad
 
 
 def _device_disassembly(tmp_path):
@@ -98,3 +157,29 @@ def test_checker_flags_the_failing_form():
     d = open(os.path.join(ROOT, "tests", "nmsexp", "disasm", "round_s3_fail_vs_nopeephole.shape.diff")).read().splitlines()
     changed = [ln for ln in d if ln[:1] in "+-" and not ln.startswith(("+++", "---"))]
     assert len(changed) == 40
+
+
+RECORD_ROUND_KERNELS = ["k_nms_phase_cILi2ELb1E", "k_nms_phase_cILi2ELb0E", "k_nms_phase_cILi3ELb1E", "k_nms_phase_cILi3ELb0E",
+                        "10k_nms_pushE", "k_nms_phase_aE"]
+
+
+def test_record_rounds_load_under_full_exec_and_evaluate_branch_free(tmp_path):
+    """k_nms_tail is not in the list on purpose: it runs the same phase_c_wave code (checked here through k_nms_phase_c) and,
+    besides it, the general path's serial leftovers, whose phases are separated by block barriers inside ONE workgroup --
+    no other workgroup's stores are in flight there."""
+    dis = _device_disassembly(tmp_path)
+    for needle in RECORD_ROUND_KERNELS:
+        fn = _function(dis, needle)
+        assert len(fn) > 300, needle + " not found in libpgx.so"
+        wins = record_load_windows(_instructions(fn))
+        assert len(wins) >= 1, needle + ": no record loads found, re-derive the check"
+        for k, w in wins:
+            bad = exec_ops_between_load_and_use(w)
+            assert not bad, "%s: record load at instruction %d is followed by divergent control flow before its use: %s" % (needle, k, bad[:3])
+
+
+def test_record_round_checker_flags_the_round3_form():
+    path = os.path.join(ROOT, "tests", "nmsexp", "disasm", "phase_c_r3_predicated.s")
+    wins = record_load_windows(_instructions(open(path).read().splitlines()))
+    flagged = [k for k, w in wins if exec_ops_between_load_and_use(w)]
+    assert len(flagged) >= 4, flagged   # the two predicated loads of the exact test and of the suppression walk
