@@ -21,7 +21,13 @@
  *     context's stream and return immediately; data errors surface in pgx_check_status().
  *   - The caller owns every buffer; the library keeps no caller pointer after a call returns.
  *   - One context per GPU.  Calls on one context are serialised by an internal mutex
- *     (the reference never re-enters a stage: TestService.cs:25,137-152).
+ *     (the reference never re-enters a stage: TestService.cs:25,137-152), so a context may be called from several host
+ *     threads -- the reference's pipeline runs ApplyDistortionMat on image k + 1 beside Detect on image k
+ *     (TestService.cs:25,146-149) -- but its stages then run one after the other; one context per stage (each with its own
+ *     configuration and workspaces) lets them overlap on the device.  tests/test_gpu_threads.py covers both.
+ *   - pgx_last_error(ctx) is per calling thread: it returns the text of that thread's most recent failing call on ctx
+ *     (valid until the thread's next failing call or next pgx_last_error); a thread that has not failed on ctx gets a copy
+ *     of the most recent failure of any thread.
  */
 #ifndef PGX_H
 #define PGX_H
@@ -204,7 +210,12 @@ int pgx_allgather_dev(pgx_ctx *ctx, void *d_buf, size_t bytes_per_rank);
  * of d_desc_all [world * frame_slots][capacity][words] / d_counts_all [world * frame_slots]; all-gather both; match this
  * rank's n_local_pairs image pairs (d_pairlist_local [n][2] = SLOT indices into the gathered buffers) into its block of
  * d_out_all [world * pair_slots][capacity]; all-gather the lists.  Lists are cut to `capacity` by pgx_set_capacity's
- * survivor limit (set it <= capacity).  world == 1: the same without the collectives. */
+ * survivor limit (set it <= capacity).  world == 1: the same without the collectives.
+ * Errors at world > 1: every rank-local check and allocation happens before the first collective, and the first call with a
+ * given set of arguments ends that part with a status exchange among the ranks: if any rank fails there, EVERY rank returns
+ * (the failing one its own code, the others PGX_E_RCCL naming it) and nothing has been exchanged.  A HIP / RCCL failure later
+ * in the step aborts this rank's communicator (best effort: peers blocked in a collective may not notice on one node -- the
+ * host must put a time limit on its ranks) and leaves the context without one. */
 int pgx_sequence_step_dev(pgx_ctx *ctx, const uint16_t *d_frames_local, int n_local_frames, int frame_slots, int W, int H,
                           pgx_keypoint *d_kp_local, uint32_t *d_desc_all, int32_t *d_counts_all, int32_t *d_nraw_local,
                           int capacity, const int32_t *d_pairlist_local, int n_local_pairs, int pair_slots,

@@ -12,6 +12,19 @@
 
 #define PGX_VERSION_STR "pgx 0.1 (gfx950)"
 
+static thread_local std::string tl_err;
+static thread_local const pgx_ctx *tl_err_ctx = nullptr;
+
+void pgx_note_error(pgx_ctx *c, const std::string &msg)
+{
+    tl_err = msg;
+    tl_err_ctx = c;
+    if (c) {
+        std::lock_guard<std::mutex> g(c->err_mu);
+        c->err = msg;
+    }
+}
+
 namespace {
 
 int fail(pgx_ctx *c, int code, const char *fmt, ...)
@@ -21,7 +34,7 @@ int fail(pgx_ctx *c, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->err = buf;
+    pgx_note_error(c, buf);
     return code;
 }
 
@@ -305,7 +318,17 @@ void pgx_ctx_destroy(pgx_ctx *c)
     delete c;
 }
 
-const char *pgx_last_error(pgx_ctx *c) { return c ? c->err.c_str() : "null context"; }
+const char *pgx_last_error(pgx_ctx *c)
+{
+    if (!c) return "null context";
+    if (tl_err_ctx == c) return tl_err.c_str();   // this thread's own last failure on this context
+    static thread_local std::string copy;         // another thread's: a private copy, valid until this thread asks again
+    {
+        std::lock_guard<std::mutex> g(c->err_mu);
+        copy = c->err;
+    }
+    return copy.c_str();
+}
 
 int pgx_set_stream(pgx_ctx *c, void *hip_stream)
 {

@@ -10,9 +10,12 @@
 //
 // Failure on ONE rank: a collective is a rendezvous, so a rank that returned early would leave its peers waiting in the
 // all-gather for ever.  pgx_sequence_step_dev therefore does every rank-local check and every workspace allocation BEFORE
-// the first collective, and if a local call still fails after that point it aborts the communicator (ncclCommAbort): the
-// peers' pending collectives then fail with PGX_E_RCCL instead of hanging, and this context is left without a communicator.
-// N > 1 on RCCL has only ever run under the driver's multi-GPU bench (the development box has one GPU).
+// the first collective and -- on the first call with a given set of arguments -- ends that part with a one-int status
+// exchange that the failing rank joins too: every rank returns an error, nobody waits.  A HIP or RCCL error in the middle
+// of a step (after that point) makes the rank abort its communicator (ncclCommAbort, a required symbol); that is best
+// effort: on one node the peers' collective kernels may spin on shared flags without noticing, so the host must time
+// its ranks out.  N > 1 on RCCL has only ever run under the driver's multi-GPU bench (the development box has one GPU);
+// the agreement logic is rehearsed on CPU through its torch twin (dist.ShardedSequence, tests/test_dist_gloo.py).
 #include "pgx_internal.h"
 
 #include <dlfcn.h>
@@ -34,7 +37,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr; // optional
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
@@ -63,7 +66,7 @@ Rccl *rccl()
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.h, "ncclAllGather"));
         r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.h, "ncclCommAbort"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.h, "ncclGetErrorString"));
-        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) r.err = "librccl lacks an expected nccl* symbol";
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.CommAbort) r.err = "librccl lacks an expected nccl* symbol";
     });
     return &r;
 }
@@ -73,7 +76,7 @@ int comm_fail(pgx_ctx *c, const char *what, ncclResult_t rc)
     Rccl *r = rccl();
     char buf[256];
     snprintf(buf, sizeof buf, "%s: %s", what, (r->GetErrorString && rc) ? r->GetErrorString(rc) : (r->err.empty() ? "RCCL error" : r->err.c_str()));
-    if (c) c->err = buf;
+    pgx_note_error(c, buf);
     return PGX_E_RCCL;
 }
 
@@ -102,10 +105,10 @@ int pgx_comm_unique_id(void *id_out)
 
 int pgx_comm_init(pgx_ctx *c, int rank, int world, const void *id)
 {
-    if (!c || !id || world < 1 || rank < 0 || rank >= world) return c ? (c->err = "bad rank/world", PGX_E_BADARG) : PGX_E_BADARG;
+    if (!c || !id || world < 1 || rank < 0 || rank >= world) return c ? (pgx_note_error(c, "bad rank/world"), PGX_E_BADARG) : PGX_E_BADARG;
     std::lock_guard<std::mutex> g(c->mu);
     (void)hipSetDevice(c->device);
-    if (c->comm) { c->err = "communicator already initialised"; return PGX_E_BADARG; }
+    if (c->comm) { pgx_note_error(c, "communicator already initialised"); return PGX_E_BADARG; }
     Rccl *r = rccl();
     if (!r->err.empty()) return comm_fail(c, "pgx_comm_init", 0);
     ncclUniqueId uid;
@@ -144,7 +147,7 @@ int pgx_comm_info(pgx_ctx *c, int *rank, int *world)
 static int allgather_locked(pgx_ctx *c, void *d_buf, size_t bytes_per_rank)
 {
     if (c->comm_world <= 1 || bytes_per_rank == 0) return PGX_OK; // one rank: the buffer already is the gathered one
-    if (!c->comm) { c->err = "pgx_comm_init not called"; return PGX_E_NOT_CONFIGURED; }
+    if (!c->comm) { pgx_note_error(c, "pgx_comm_init not called"); return PGX_E_NOT_CONFIGURED; }
     const char *send = reinterpret_cast<const char *>(d_buf) + (size_t)c->comm_rank * bytes_per_rank; // in place
     const ncclResult_t rc = rccl()->AllGather(send, d_buf, bytes_per_rank, ncclUint8V, reinterpret_cast<ncclComm_t>(c->comm), c->stream);
     return rc == ncclSuccessV ? PGX_OK : comm_fail(c, "ncclAllGather", rc);
@@ -166,23 +169,59 @@ int pgx_sequence_step_dev(pgx_ctx *c, const uint16_t *d_frames_local, int n_loca
     if (!c || !d_desc_all || !d_counts_all || !d_out_all || capacity <= 0 || frame_slots < 0 || pair_slots < 0 ||
         n_local_frames < 0 || n_local_frames > frame_slots || n_local_pairs < 0 || n_local_pairs > pair_slots ||
         (n_local_frames > 0 && (!d_frames_local || !d_kp_local || !d_nraw_local)) || (n_local_pairs > 0 && !d_pairlist_local))
-        return c ? (c->err = "bad argument", PGX_E_BADARG) : PGX_E_BADARG;
+        return c ? (pgx_note_error(c, "bad argument"), PGX_E_BADARG) : PGX_E_BADARG;
     std::lock_guard<std::mutex> g(c->mu);
     (void)hipSetDevice(c->device);
-    if (!c->pairs_set) { c->err = "pgx_set_brief_pairs not called"; return PGX_E_NOT_CONFIGURED; }
-    if (c->comm_world > 1 && !c->comm) { c->err = "pgx_comm_init not called"; return PGX_E_NOT_CONFIGURED; }
+    if (c->comm_world > 1 && !c->comm) { pgx_note_error(c, "pgx_comm_init not called"); return PGX_E_NOT_CONFIGURED; }
     const int words = c->words, r = c->comm_rank;
-    // every rank-local check and allocation first: nothing below this block fails for a local reason in normal operation
-    int rc = pgx_prepare_detect(c, n_local_frames, W, H, capacity);
+    // Every rank-local check and allocation first: nothing below this block fails for a local reason in normal operation.
+    // A rank that does fail here (not configured, a size mismatch, no memory) must not leave its peers waiting in the first
+    // all-gather, so the FIRST call with a given set of arguments ends this block with a status exchange -- one int per rank
+    // through the same all-gather, which the failing rank joins too -- and every rank returns an error if any rank failed.
+    // The failures in question are properties of the arguments and of what is already allocated (workspaces only grow), so
+    // later calls with the same arguments skip the exchange: it costs a host synchronisation.
+    int rc = PGX_OK;
+    if (!c->pairs_set) { pgx_note_error(c, "pgx_set_brief_pairs not called"); rc = PGX_E_NOT_CONFIGURED; }
+    if (rc == PGX_OK) rc = pgx_prepare_detect(c, n_local_frames, W, H, capacity);
     if (rc == PGX_OK) rc = pgx_prepare_match(c, capacity, words, n_local_pairs);
-    if (rc != PGX_OK) return rc;   // before any collective: the peers see this rank's error through the host, not a hang
-    // from here on a local failure aborts the communicator so that the peers' collectives fail instead of waiting
+    if (c->comm_world > 1) {
+        char key[160];
+        snprintf(key, sizeof key, "%d/%d/%dx%d/%d/%d/%d/%d/%d", n_local_frames, frame_slots, W, H, capacity, n_local_pairs, pair_slots,
+                 words, c->radius);
+        if (rc != PGX_OK || c->comm_agreed != key) {
+            const std::string own = rc != PGX_OK ? std::string(pgx_last_error(c)) : std::string();
+            const int G = c->comm_world;
+            std::vector<int> st((size_t)G, 0);
+            st[(size_t)r] = rc;
+            int xrc = PGX_OK;
+            if (c->ws_agree.ensure((size_t)G * sizeof(int)) != hipSuccess ||
+                hipMemcpyAsync(c->ws_agree.p, st.data(), (size_t)G * sizeof(int), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+                xrc = PGX_E_HIP;
+            if (xrc == PGX_OK) xrc = allgather_locked(c, c->ws_agree.p, sizeof(int));
+            if (xrc == PGX_OK && (hipMemcpyAsync(st.data(), c->ws_agree.p, (size_t)G * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                                  hipStreamSynchronize(c->stream) != hipSuccess))
+                xrc = PGX_E_HIP;
+            if (rc != PGX_OK) { pgx_note_error(c, own); return rc; }   // this rank's own error, text restored
+            if (xrc != PGX_OK) { if (xrc == PGX_E_HIP) pgx_note_error(c, "status exchange before the first collective failed"); return xrc; }
+            for (int k = 0; k < G; k++)
+                if (st[(size_t)k] != PGX_OK) {
+                    char msg[160];
+                    snprintf(msg, sizeof msg, "rank %d failed before the first collective (code %d); nothing was exchanged", k, st[(size_t)k]);
+                    pgx_note_error(c, msg);
+                    return PGX_E_RCCL;
+                }
+            c->comm_agreed = key;
+        }
+    } else if (rc != PGX_OK) return rc;
+    // From here on a local failure is a HIP or RCCL error in the middle of the step.  The communicator is aborted so that
+    // the peers' collectives have a chance to fail instead of waiting -- best effort: on one node the peers' collective
+    // kernels may not notice a remote abort, and the host is expected to time its ranks out (include/pgx.h).
     auto bail = [&](int code) {
         if (c->comm_world > 1 && c->comm) {
-            Rccl *q = rccl();
-            if (q->CommAbort) (void)q->CommAbort(reinterpret_cast<ncclComm_t>(c->comm));
+            (void)rccl()->CommAbort(reinterpret_cast<ncclComm_t>(c->comm));
             c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
-            c->err += " (communicator aborted: the other ranks' collectives fail with PGX_E_RCCL)";
+            c->comm_agreed.clear();
+            pgx_note_error(c, std::string(pgx_last_error(c)) + " (communicator aborted)");
         }
         return code;
     };

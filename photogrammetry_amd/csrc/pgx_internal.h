@@ -75,7 +75,8 @@ struct pgx_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::mutex mu;
-    std::string err;
+    std::string err;     // text of the last failing call of any thread (written through pgx_note_error, under err_mu)
+    std::mutex err_mu;
 
     // configuration
     float threshold = 0.f;
@@ -114,6 +115,8 @@ struct pgx_ctx {
     // multi-GPU: the RCCL communicator of this context's process (pgx_comm.hip); world 1 = none
     void *comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    std::string comm_agreed;   // arguments of the last pgx_sequence_step_dev whose local part every rank confirmed
+    DevBuf ws_agree;
 
     // profiling
     bool prof_on = false;
@@ -146,6 +149,9 @@ __device__ __forceinline__ void pgx_xcd_map(int lin, int nblk, int F, int &f, in
     }
 }
 #endif
+
+// error text of a failing call: kept per calling thread (what pgx_last_error returns to that thread) and on the context
+void pgx_note_error(pgx_ctx *c, const std::string &msg);
 
 // RAII event bracket used by the launchers' callers
 // attach = true: the scope records nothing itself; the ONE kernel launched inside it takes the two events with

@@ -212,6 +212,7 @@ class ShardedSequence:
         self.counts_all = torch.zeros(G * self.fs, **i32)
         self.out_bufs = [torch.zeros((G * self.ps, nkp, 3), **i32) for _ in range(2 if (self.overlap and G > 1) else 1)]
         self._cur = 0
+        self._agreed = False   # the ranks have agreed once that the first step's local part went through (see step)
         self.out_all = self.out_bufs[0]
         self.kp_l = torch.zeros((self.fs, nkp, 4), **i32)
         self.nraw_l = torch.zeros(self.fs, **i32)
@@ -233,9 +234,30 @@ class ShardedSequence:
                                      self.nraw_l, self.nkp, self.pairlist_l, npr, self.ps, self.out_all)
             return
         with (torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()):
-            if nf:
-                self.e.detect_batch_dev(d_frames_local, nf, self.W, self.H, self.kp_l, self.desc_l, self.counts_l,
-                                        self.nraw_l, self.nkp)
+            # A rank whose local part fails before the first collective (not configured, a size mismatch, no memory for a
+            # workspace: all of them properties of the configuration, raised by the first call) must not leave its peers
+            # waiting in the all-gather: the first step ends its local part with a one-word status exchange, and every rank
+            # raises if any rank failed.  Later steps with the same buffers cannot fail that way and skip the exchange (it
+            # would cost a host synchronisation per step).
+            local_error = None
+            try:
+                if nf:
+                    self.e.detect_batch_dev(d_frames_local, nf, self.W, self.H, self.kp_l, self.desc_l, self.counts_l,
+                                            self.nraw_l, self.nkp)
+            except Exception as ex:  # noqa: BLE001 -- whatever it is, the peers have to hear about it
+                if self.world == 1 or self._agreed:
+                    raise
+                local_error = ex
+            if self.world > 1 and not self._agreed:
+                st = torch.full((1,), 0 if local_error is None else 1, dtype=torch.int32, device=self.desc_all.device)
+                st_all = torch.zeros(self.world, dtype=torch.int32, device=self.desc_all.device)
+                dist.all_gather_into_tensor(st_all, st, group=self.group)
+                bad = [r for r, v in enumerate(st_all.cpu().tolist()) if v]
+                if local_error is not None:
+                    raise local_error
+                if bad:
+                    raise RuntimeError("rank(s) %s failed before the first exchange; no collective was started" % bad)
+                self._agreed = True
             if self.world > 1:
                 dist.all_gather_into_tensor(self.desc_all, self.desc_l, group=self.group)
                 dist.all_gather_into_tensor(self.counts_all, self.counts_l, group=self.group)

@@ -228,3 +228,51 @@ def test_slot_of_is_a_bijection():
             for r in range(world):   # rank r's block holds exactly its items, in ownership order
                 assert [pdist.slot_of(i, world, ns) for i in pdist.local_items(n, r, world)] == \
                        list(range(r * ns, r * ns + len(pdist.local_items(n, r, world))))
+
+
+# ---- a rank that fails before the first exchange must not leave its peers waiting (pgx_comm.hip / dist.py) ----
+
+class _FailingEngine(_OracleEngine):
+    def detect_batch_dev(self, *a, **k):
+        raise ValueError("pgx_set_detect_params not called")   # what an unconfigured context answers
+
+
+def _fail_worker(rank, world, port, q, bad_rank):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pairs = cref.gaussian_pairs(0, 20, 256)
+        fr = _frames()
+        pl = pdist.all_pairs(N_FRAMES)
+        eng = _FailingEngine(pairs) if rank == bad_rank else _OracleEngine(pairs)
+        job = pdist.ShardedSequence(eng, W, H, N_FRAMES, pl, CAP, 8, "cpu")
+        mine = torch.from_numpy(np.stack([fr[f] for f in job.my_frames]))
+        try:
+            job.step(mine)
+            q.put((rank, "no error"))
+        except Exception as ex:  # noqa: BLE001
+            q.put((rank, "%s: %s" % (type(ex).__name__, ex)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("world,bad_rank", [(2, 1), (3, 0)])
+def test_rank_failing_before_the_first_exchange_fails_every_rank(world, bad_rank):
+    """One rank's local part raises before any collective: every rank must come back with an error (the failing one with
+    its own, the others naming it) instead of waiting in the all-gather -- the whole test would time out otherwise."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fail_worker, args=(r, world, port, q, bad_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert results[bad_rank].startswith("ValueError: pgx_set_detect_params not called")
+    for r in range(world):
+        if r != bad_rank:
+            assert results[r].startswith("RuntimeError: rank(s) [%d] failed before the first exchange" % bad_rank), results[r]

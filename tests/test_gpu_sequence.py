@@ -407,3 +407,35 @@ def test_detect_batch_every_frame_repeated(engine, radius):
             assert cnt[f] == len(kept), (rep, f, cnt[f], len(kept))
             assert (kp[f, :cnt[f], 0] == kept["x"]).all() and (kp[f, :cnt[f], 1] == kept["y"]).all(), (rep, f)
             assert (kp[f, :cnt[f], 2] == kept["fast_score"]).all(), (rep, f)
+
+
+# ---- matcher sizes beyond BASELINE's (the reference has no cap on N: KeypointMatching.cs:20-35) -------------------------
+
+def _hub_sets(n1, n2, protos, seed):
+    """the generator of test_gpu_parity.py::test_match_duplicate_and_hub_descriptors: many identical and low-popcount
+    "hub" descriptors (tie chains, one acceptance per cluster and round)"""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 2**32, (protos, 8), dtype=np.uint32)
+    base[: max(1, protos // 4)] &= rng.integers(0, 2**32, (max(1, protos // 4), 8), dtype=np.uint32) & 0x11111111
+    d1 = base[rng.integers(0, protos, n1)].copy()
+    d2 = base[rng.integers(0, protos, n2)].copy()
+    flip = rng.random(n1) < 0.3
+    d1[flip, 0] ^= np.uint32(1) << rng.integers(0, 32, int(flip.sum())).astype(np.uint32)
+    return d1, d2
+
+
+@pytest.mark.parametrize("n1,n2,kind", [(12000, 9000, "random"), (20000, 300, "random"), (300, 20000, "random"), (9000, 9000, "hub")])
+def test_match_sizes_beyond_the_bench(engine, n1, n2, kind):
+    """pgx_match through the 256-bit path at sizes where a set no longer fits one column chunk of the distance kernel
+    (4096 columns, 7-bit tile field), where the plan needs 4-6 whole-chip rounds, and at very unequal sides; against the
+    oracle's sorted-edge-scan matcher, bit for bit (indices, distances, the (0, 0, int.MaxValue) tail of n1 > n2)."""
+    if kind == "random":
+        d1, d2 = synth.random_descriptors(n1, 8, 7000 + n1), synth.random_descriptors(n2, 8, 9000 + n2)
+    else:
+        d1, d2 = _hub_sets(n1, n2, 1500, n1 + n2)
+    got = engine.match(d1, d2)
+    exp = cref.match_sorted(d1, d2)
+    assert len(got) == n1
+    assert (got["k1"] == exp["k1"]).all() and (got["k2"] == exp["k2"]).all() and (got["dist"] == exp["dist"]).all()
+    if n1 > n2:
+        assert int((got["dist"] == pg.api.PGX_DIST_NONE).sum()) == n1 - n2

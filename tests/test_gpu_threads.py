@@ -1,0 +1,166 @@
+"""The boundary's threading contract on the GPU (SURVEY 8b "Threading"): the reference's pipeline runs ApplyDistortionMat on
+image k + 1 while Detect runs on image k (Photogrammetry/TestService.cs:25,146-149: DataflowBlockOptions with
+MaxDegreeOfParallelism, one block per stage).  libpgx.so answers with one mutex per context (csrc/pgx_internal.h), and
+INTEGRATION.md recommends one context per stage.  Both forms are run from real host threads here (ctypes releases the GIL for
+the duration of a call), every result against the CPU oracle; plus pgx_last_error's per-thread behaviour (include/pgx.h)."""
+import threading
+
+import numpy as np
+import pytest
+
+import photogrammetry_amd as pg
+from oracle import cref
+from photogrammetry_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+W, H, T, RADIUS, CAP = 640, 360, np.float32(0.1), 12, 4096
+COEFFS = [3e-4, 1e-7, 0, 0, 0]
+N_FRAMES = 6
+
+
+def _configure(e, pairs, dmap):
+    e.set_brief_pairs(pairs)
+    e.set_detect_params(T, RADIUS)
+    e.set_capacity(1 << 17, CAP)
+    e.set_dewarp_map(dmap)
+
+
+def _oracle(frames, pairs, dmap):
+    exp = []
+    for f in frames:
+        dw = cref.apply_distortion(f, dmap)
+        g = cref.gray(dw)
+        raw = cref.detect(g, T)
+        kept = raw[cref.nms(raw, RADIUS)]
+        desc = cref.brief(g, np.stack([kept["x"], kept["y"]], 1), pairs)
+        exp.append(dict(dewarped=dw, gray=cref.gray(f), kept=kept, desc=desc))
+    return exp
+
+
+def _run(stage_engines, frames, pairs, dmap):
+    """Thread A: pgx_dewarp + pgx_gray on frame k + 1 in a loop; thread B: pgx_detect on frame k and pgx_match of frames k - 1, k."""
+    e_a, e_b = stage_engines
+    out_a, out_b, errors = {}, {}, []
+    start = threading.Barrier(2)
+
+    def stage_a():
+        try:
+            start.wait()
+            for rep in range(3):
+                for k, f in enumerate(frames):
+                    out_a[k] = (e_a.dewarp(f), e_a.gray(f))
+        except Exception as ex:  # noqa: BLE001
+            errors.append(("A", ex))
+
+    def stage_b():
+        try:
+            start.wait()
+            prev = None
+            for k, f in enumerate(frames):
+                kp, desc, _ = e_b.detect(f, capacity=CAP)
+                m = e_b.match(prev[1], desc) if prev is not None and len(prev[1]) and len(desc) else None
+                out_b[k] = (kp, desc, m)
+                prev = (kp, desc)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(("B", ex))
+
+    ta, tb = threading.Thread(target=stage_a), threading.Thread(target=stage_b)
+    ta.start(); tb.start()
+    ta.join(120); tb.join(120)
+    assert not ta.is_alive() and not tb.is_alive(), "a stage thread is stuck"
+    assert not errors, errors
+    return out_a, out_b
+
+
+def _check(out_a, out_b, exp):
+    for k, x in enumerate(exp):
+        dw, g = out_a[k]
+        assert (dw == x["dewarped"]).all(), k
+        assert g.view(np.uint32).tobytes() == x["gray"].view(np.uint32).tobytes(), k
+        kp, desc, m = out_b[k]
+        assert len(kp) == len(x["kept"]), k
+        for fld in ("x", "y", "fast_score"):
+            assert (kp[fld] == x["kept"][fld]).all(), (k, fld)
+        assert (desc == x["desc"]).all(), k
+        if k > 0 and m is not None:
+            e = cref.match_sorted(exp[k - 1]["desc"], x["desc"])
+            assert (m["k1"] == e["k1"]).all() and (m["k2"] == e["k2"]).all() and (m["dist"] == e["dist"]).all(), k
+
+
+@pytest.fixture(scope="module")
+def job():
+    base = synth.make_frame(W, H, seed=11, n_shapes=1500)
+    frames = [synth.shift_frame(base, 3 * i, i) for i in range(N_FRAMES)]
+    pairs = pg.make_brief_pairs(0, 20, 256)
+    dmap = pg.build_dewarp_map(W, H, COEFFS)
+    return frames, pairs, dmap, _oracle(frames, pairs, dmap)
+
+
+def test_two_host_threads_on_one_context(job):
+    frames, pairs, dmap, exp = job
+    e = pg.Engine(0)
+    try:
+        _configure(e, pairs, dmap)
+        out_a, out_b = _run((e, e), frames, pairs, dmap)
+        _check(out_a, out_b, exp)
+    finally:
+        e.close()
+
+
+def test_one_context_per_stage(job):
+    """INTEGRATION.md's recommendation: the stages overlap on the device, each context owns its map and workspaces."""
+    frames, pairs, dmap, exp = job
+    ea, eb = pg.Engine(0), pg.Engine(0)
+    try:
+        _configure(ea, pairs, dmap)
+        _configure(eb, pairs, dmap)
+        out_a, out_b = _run((ea, eb), frames, pairs, dmap)
+        _check(out_a, out_b, exp)
+    finally:
+        ea.close(); eb.close()
+
+
+def test_last_error_is_per_thread():
+    """Two threads fail on ONE context with different errors at the same time, many times: each must read its own text."""
+    e = pg.Engine(0)
+    L = pg._lib.lib()
+    bad = []
+    start = threading.Barrier(2)
+
+    def fail_dims():   # DeWarp.cs:22-23 -> PGX_E_DIM_MISMATCH
+        e.set_dewarp_map(np.zeros((20, 30, 2), dtype=np.int32))
+        start.wait()
+        for _ in range(200):
+            try:
+                e.dewarp(np.zeros((21, 30, 4), dtype=np.uint16))
+                bad.append("dims: no error")
+            except pg.ArgumentException as ex:
+                if "dewarp map" not in str(ex):
+                    bad.append("dims thread read: " + str(ex))
+
+    def fail_empty():  # KeypointMatching.cs:61 -> PGX_E_EMPTY_SET
+        d = np.ones((4, 8), dtype=np.uint32)
+        start.wait()
+        for _ in range(200):
+            try:
+                e.match(d, np.zeros((0, 8), dtype=np.uint32))
+                bad.append("empty: no error")
+            except pg.ArgumentOutOfRangeException as ex:
+                if "keypoints2 is empty" not in str(ex):
+                    bad.append("empty thread read: " + str(ex))
+
+    try:
+        ts = [threading.Thread(target=fail_dims), threading.Thread(target=fail_empty)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(120)
+        assert not bad, bad[:5]
+        # a thread that never failed on the context reads the most recent failure of any thread
+        got = []
+        t = threading.Thread(target=lambda: got.append(L.pgx_last_error(e._h).decode()))
+        t.start(); t.join(30)
+        assert got and ("dewarp map" in got[0] or "keypoints2 is empty" in got[0]), got
+    finally:
+        e.close()
