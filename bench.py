@@ -593,7 +593,9 @@ def worker(args):
                     "matrix_dtype": "fp4 e2m1 (+-1, exact), f32 accumulate, block scale 2^13" if MFMA_FP4 else "int8 (+-64), i32 accumulate",
                     "frac_of_int8_peak": ops / tt / 5.0e15,
                     "algorithmic": "2*P = 512 ops per descriptor-pair evaluation x %d evaluations per step "
-                                   "(device-counted: sum over launches and image pairs of n1*n2; %d wide rounds per chunk of 256 pairs)"
+                                   "(device-counted: sum over launches and image pairs of n1*n2 of the whole-chip rounds; %d planned per "
+                                   "chunk of image pairs, of which the spare one exits early on this workload; the residual R x C "
+                                   "distances that k_tail_rows_fp4 evaluates once more are NOT counted)"
                                    % (evals, rounds_wide)}
             if "ham_argmin" in kern_alone:
                 ta = kern_alone["ham_argmin"]["ms_per_step"] * 1e-3
@@ -618,8 +620,9 @@ def worker(args):
                      "integer keys); f32 grey",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] (SURVEY 8d config 3) x %d: %d-frame 1920x1080 RGBA64 sequence(s), "
-                                   "dewarp(%s)+gray+FAST(T=0.1)+NMS(r=%d)+BRIEF-256 per frame, all %d ordered image pairs per sequence "
-                                   "through the greedy Hamming match, <=%d keypoints per frame (first %d in NMS order)"
+                                   "dewarp(%s)+gray+FAST(T=0.1)+NMS(r=%d; SURVEY 8d writes r = 20 for this config: both leave more than 4096 "
+                                   "survivors per frame, the lists are cut to the same length either way)+BRIEF-256 per frame, all %d ordered "
+                                   "image pairs per sequence through the greedy Hamming match, <=%d keypoints per frame (first %d in NMS order)"
                                    % (nseq, FS, "off" if dmap is None else "shipped coeffs", RADIUS, FS * (FS - 1) // 2, NKP, NKP),
                        "frames": n_frames, "image_pairs": len(pair_list), "frames_per_gpu": F_l, "image_pairs_per_gpu": M_l,
                        "descriptor_pairs_per_step": pairs_per_step,

@@ -17,7 +17,7 @@ internal static unsafe class PgxNative
     private const string Lib = "pgx"; // libpgx.so next to the executable or on LD_LIBRARY_PATH
 
     public const int Ok = 0, EDimMismatch = 1, EOobSource = 2, EEmptySet = 3, ECapacity = 4, EBadArg = 5, EHip = 6,
-        ENotConfigured = 7;
+        ENotConfigured = 7, ERccl = 8;   // include/pgx.h:37-45
 
     [DllImport(Lib)] public static extern int pgx_ctx_create(int device, out IntPtr ctx);
     [DllImport(Lib)] public static extern void pgx_ctx_destroy(IntPtr ctx);
@@ -76,6 +76,7 @@ internal static unsafe class PgxNative
             EDimMismatch or EBadArg => new ArgumentException(msg),          // DeWarp.cs:23, :48
             EOobSource => new IndexOutOfRangeException(msg),                // Matrix.cs:65, :207
             EEmptySet => new ArgumentOutOfRangeException(msg),              // KeypointMatching.cs:61
+            ERccl => new System.IO.IOException(msg),                        // a collective or the RCCL library failed (multi-GPU only)
             _ => new InvalidOperationException(msg),
         };
     }

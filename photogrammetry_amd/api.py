@@ -189,6 +189,9 @@ class Engine:
         F = len(descs)
         arrs = [np.ascontiguousarray(d, dtype=np.uint32) for d in descs]
         words = next((a.shape[1] for a in arrs if a.ndim == 2 and a.shape[0]), 8)
+        for f, a in enumerate(arrs):   # the library copies counts[f] * words words from every descs[f]
+            if len(a) and (a.ndim != 2 or a.shape[1] != words):
+                raise ValueError("descs[%d] has shape %s; every non-empty set must be [n][%d]" % (f, a.shape, words))
         counts = np.array([len(a) for a in arrs], dtype=np.int32)
         ptrs = (C.c_void_p * max(1, F))(*[a.ctypes.data if len(a) else None for a in arrs])
         pl = np.ascontiguousarray(pair_list, dtype=np.int32).reshape(-1, 2)

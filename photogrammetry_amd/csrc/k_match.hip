@@ -17,12 +17,13 @@
 //
 // Kernels
 //   k_match_init      identity lists, keys, counters
-//   k_ham_mfma        (256-bit descriptors) int8 MFMA distance + fused row/column argmin, k_match_mfma.inc
-//   k_ham_valu        xor+popcount distance/argmin for any descriptor length (or PGX_DISABLE_MFMA=1)
+//   k_ham_fp4         (256-bit descriptors) block-scaled FP4 MFMA distance + fused row/column argmin, k_match_mfma.inc
+//   k_ham_valu        xor+popcount distance/argmin for any other descriptor length
 //   k_match_select    one workgroup per image pair: accept mutual edges, compact the lists
-//   256-bit descriptors, once a pair's residual is <= PGX_TAIL_MAX (k_match_tail.inc, k_match_mfma.inc):
-//   k_tail_rows_mfma  residual distance rows (u8) + every row's nearest column, on the matrix pipe
-//   k_match_gs        one workgroup per image pair: row-proposing deferred acceptance, sort, the N1 output entries
+//   256-bit descriptors, once a pair's residual is <= PGX_TAIL_MAX (k_match_mfma.inc, k_match_tail.inc):
+//   k_tail_rows_fp4   residual distance rows (u8) + every row's nearest column, on the matrix pipe
+//   k_match_gs        one workgroup per image pair: row-proposing deferred acceptance off a queue of free rows (no rounds),
+//                     sort by (dist, k1), the N1 output entries
 //   other descriptor lengths:
 //   k_match_finish    one workgroup per image pair: remaining rounds in-kernel (LDS tail below PGX_TAIL_FILL_MAX),
 //                     sort (bitonic, LDS), the N1 output entries

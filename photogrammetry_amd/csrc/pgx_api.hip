@@ -598,12 +598,14 @@ int pgx_match_batch(pgx_ctx *c, const uint32_t *const *descs, const int32_t *cou
         return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
     Lock l(c);
     if (words <= 0 || words > 127) return fail(c, PGX_E_BADARG, "words must be in [1, 127]");
-    int S = 1;
     for (int f = 0; f < n_frames; f++) {
         if (counts[f] < 0 || counts[f] > (1 << PGX_IDX_BITS)) return fail(c, PGX_E_BADARG, "counts[%d] = %d", f, counts[f]);
         if (counts[f] > 0 && !descs[f]) return fail(c, PGX_E_BADARG, "descs[%d] is null", f);
-        if (counts[f] > S) S = counts[f];
     }
+    // the slot size S (descriptor slots per frame, entries per list) is the largest set that some image pair REFERENCES:
+    // a large frame nobody matches costs neither upload nor workspace nor download
+    int S = 1;
+    std::vector<char> used((size_t)(n_frames > 0 ? n_frames : 1), 0);
     int64_t total = 0;
     bool empty_set = false;
     for (int m = 0; m < n_pairs; m++) {
@@ -612,6 +614,9 @@ int pgx_match_batch(pgx_ctx *c, const uint32_t *const *descs, const int32_t *cou
         if (out_offsets) out_offsets[m] = total;
         total += counts[fa];
         if (counts[fa] > 0 && counts[fb] == 0) empty_set = true;
+        used[(size_t)fa] = used[(size_t)fb] = 1;
+        if (counts[fa] > S) S = counts[fa];
+        if (counts[fb] > S) S = counts[fb];
     }
     if (out_offsets) out_offsets[n_pairs] = total;
     if (n_pairs == 0 || total == 0) return PGX_OK;
@@ -626,8 +631,8 @@ int pgx_match_batch(pgx_ctx *c, const uint32_t *const *descs, const int32_t *cou
     HIPCHK(c, c->st_c.ensure(out_bytes));
     uint8_t *hin = c->pin_in.as<uint8_t>();
     for (int f = 0; f < n_frames; f++)
-        if (counts[f] > 0) memcpy(hin + (size_t)f * S * words * 4, descs[f], (size_t)counts[f] * words * 4);
-    memcpy(hin + desc_bytes, counts, (size_t)n_frames * 4);
+        if (counts[f] > 0 && used[(size_t)f]) memcpy(hin + (size_t)f * S * words * 4, descs[f], (size_t)counts[f] * words * 4);
+    memcpy(hin + desc_bytes, counts, (size_t)n_frames * 4); // an unreferenced frame's count is never read on the device
     memcpy(hin + desc_bytes + cnt_bytes, pair_list, pl_bytes);
     HIPCHK(c, hipMemcpyAsync(c->st_a.p, hin, in_bytes, hipMemcpyHostToDevice, c->stream));
     uint8_t *din = c->st_a.as<uint8_t>();

@@ -231,12 +231,19 @@ class KeypointMatching {
         for (int f = 0; f < F; f++) {
             counts[f] = (int32_t)frames[f].size();
             packed[f].resize((size_t)counts[f] * words);
-            for (int i = 0; i < counts[f]; i++)
+            for (int i = 0; i < counts[f]; i++) {
+                if ((int)frames[f][i].BriefDescriptor.size() != words)
+                    throw ArgumentException("MatchKeypointsBatch: descriptors of different lengths");
                 std::copy(frames[f][i].BriefDescriptor.begin(), frames[f][i].BriefDescriptor.end(), packed[f].begin() + (size_t)i * words);
+            }
             ptrs[f] = packed[f].data();
         }
         size_t total = 0;
-        for (int m = 0; m < M; m++) { pl[2 * m] = pairs[m].first; pl[2 * m + 1] = pairs[m].second; total += frames[pairs[m].first].size(); }
+        for (int m = 0; m < M; m++) {
+            if (pairs[m].first < 0 || pairs[m].first >= F || pairs[m].second < 0 || pairs[m].second >= F)
+                throw ArgumentException("MatchKeypointsBatch: a pair names a frame outside the list");
+            pl[2 * m] = pairs[m].first; pl[2 * m + 1] = pairs[m].second; total += frames[pairs[m].first].size();
+        }
         std::vector<pgx_pair> out(total + 1);
         std::vector<int64_t> offs((size_t)M + 1, 0);
         ctx_.check(pgx_match_batch(ctx_.get(), ptrs.data(), counts.data(), F, words, pl.data(), M, out.data(), offs.data()));

@@ -340,3 +340,19 @@ def test_two_contexts_in_flight_are_independent():
             assert (got[:, 0] == em["k1"]).all() and (got[:, 1] == em["k2"]).all() and (got[:, 2] == em["dist"]).all()
     for e in engs:
         e.close()
+
+
+def test_match_batch_host_checks_shapes_and_ignores_unreferenced_frames(engine):
+    """a narrower / 1-D descriptor array must be refused before the library copies counts[f] * words words from
+    it; a large frame no pair references sizes nothing (slot size = the largest REFERENCED set) and changes no result."""
+    a = synth.random_descriptors(300, 8, 1)
+    b = synth.random_descriptors(280, 8, 2)
+    with pytest.raises(ValueError):
+        engine.match_batch([a, b[:, :4].copy()], [(0, 1)])
+    with pytest.raises(ValueError):
+        engine.match_batch([a, b.reshape(-1)], [(0, 1)])
+    big = synth.random_descriptors(9000, 8, 3)   # never referenced
+    got = engine.match_batch([a, big, b], [(0, 2), (2, 0)])
+    for g, (x, y) in zip(got, ((a, b), (b, a))):
+        e = cref.match_sorted(x, y)
+        assert (g["k1"] == e["k1"]).all() and (g["k2"] == e["k2"]).all() and (g["dist"] == e["dist"]).all()
