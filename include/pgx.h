@@ -99,12 +99,12 @@ int pgx_set_detect_params(pgx_ctx *ctx, float threshold, int suppression_radius)
  * no cap; default 2^20 = none).  Survivors beyond a call's own `capacity` still raise
  * PGX_E_CAPACITY. */
 int pgx_set_capacity(pgx_ctx *ctx, int max_raw_per_frame, int max_keypoints_per_frame);
-/* Image pairs per workspace chunk of pgx_match_batch_dev / pgx_sequence_step_dev (default 512, [16, 4096]).  A job with
- * more pairs goes through in chunks whose stages overlap on the device; the chunk bounds the matcher's workspace
- * (about 4.4 MiB per image pair at 4096 descriptors a side -- 4 MiB of it the residual's distance matrix --, three chunks resident:
- * 6.8 GB at the default; the largest chunk, 4096 pairs, takes 54 GB) and should be large enough that one
- * chunk's per-pair finish fills the chip (one workgroup per pair; two per CU at 512 pairs).  Results do not depend on it.
- * No reference counterpart (KeypointMatching.cs:14-69 matches one pair per call). */
+/* Image pairs per workspace chunk of pgx_match_batch_dev / pgx_sequence_step_dev (default 2048, [16, 4096]).  A job with
+ * more pairs goes through in chunks; the chunk bounds the matcher's workspace (about 4.4 MiB per image pair at 4096 descriptors
+ * a side -- 4 MiB of it the residual's distance matrix: 9 GB at the default).  Chunks of 1024 pairs or more run one after the
+ * other on the context's stream with ONE workspace; smaller chunks run their stages side by side on three streams with three
+ * workspaces resident (the form for small-memory configurations: it hides nothing once a chunk fills the chip).
+ * The per-pair finish is one workgroup per pair, so large chunks balance the CUs better.  Results do not depend on it. */
 int pgx_set_match_chunk(pgx_ctx *ctx, int image_pairs_per_chunk);
 
 /* ---- stage-granular host entry points (one reference function each) ------------------ */

@@ -149,7 +149,7 @@ int prepare_match(pgx_ctx *c, int stride, int words, int M)
     if (words <= 0 || words > 127) return fail(c, PGX_E_BADARG, "words must be in [1, 127] (P <= 4064)");
     const int CHUNK = c->match_chunk;
     const int mc = M < CHUNK ? M : CHUNK;
-    const int nws = (M <= CHUNK || c->prof_serial) ? 1 : 3;
+    const int nws = (M <= CHUNK || c->prof_serial || CHUNK >= PGX_PIPELINE_BELOW) ? 1 : 3;
     for (int k = 0; k < nws; k++) HIPCHK(c, c->ws_matchn[k].ensure(pgx_match_ws_bytes(mc, stride)));
     return PGX_OK;
 }
@@ -180,7 +180,11 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     for (int n = plan.max_n; n > plan.skip_below && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
     if (plan.rounds_mfma > 0 && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS) plan.rounds_mfma++;
     HIPCHK(c, hipMemsetAsync(c->d_status + 4, 0, PGX_MAX_WIDE_ROUNDS * 8, c->stream));
-    if (M <= CHUNK || c->prof_serial) { // everything in order on the context's stream
+    // Chunks of PGX_PIPELINE_BELOW image pairs or more go through in order on the context's stream, one workspace: every
+    // stage of the matcher is bound by vector-instruction issue, so running the stages of consecutive chunks side by side
+    // buys nothing (round 4: 6.43 ms side by side against 6.25 in order at 1024 pairs per chunk), while a large chunk gives
+    // the per-pair finish several workgroups per CU to balance (2016 pairs in one chunk: 6.0 ms).
+    if (M <= CHUNK || c->prof_serial || CHUNK >= PGX_PIPELINE_BELOW) { // everything in order on the context's stream
         for (int m0 = 0; m0 < M; m0 += CHUNK) {
             plan.M = (M - m0 < CHUNK) ? M - m0 : CHUNK;
             const int32_t *pl = d_pairlist + 2 * (size_t)m0;

@@ -30,6 +30,8 @@
 #define PGX_TAIL_MAX 2048
 // ... and the limit when the tail workgroup has to fill its distance cache itself (descriptors staged in LDS)
 #define PGX_TAIL_FILL_MAX 1024
+// chunks of at least this many image pairs run in order on one stream; smaller ones through the three-stream pipeline
+#define PGX_PIPELINE_BELOW 1024
 
 struct DevBuf {
     void *p = nullptr;
@@ -90,10 +92,11 @@ struct pgx_ctx {
     DevBuf d_map;
     int raw_cap = 1 << 17;
     int kp_cap = 1 << PGX_IDX_BITS; // soft survivor limit of the fused path (pgx_set_capacity); default: none
-    // image pairs per matcher workspace chunk (pgx_set_match_chunk).  The per-pair finish is one workgroup per image pair: 128
-    // left three quarters of the chip idle during a chunk's finish; with 512 two finish workgroups share a CU and fill each
-    // other's waits (stand-alone finish of the bench job's 2016 pairs: 2.15 ms at 256, 1.70 at 512; step 8.22 -> 8.09 ms)
-    int match_chunk = 512;
+    // image pairs per matcher workspace chunk (pgx_set_match_chunk).  The per-pair finish is one workgroup per image pair, and
+    // the pairs of a sequence differ 3:1 in how long they take: the more of them one launch holds, the better the CUs are
+    // balanced (stand-alone finish of the bench job's 2016 pairs: 2.15 ms at 256 pairs per chunk, 1.70 at 512, 1.24 in one
+    // chunk; whole matcher 6.58 / 6.43 / 6.00 ms).  4.4 MiB of workspace per pair: 9 GB at the default.
+    int match_chunk = 2048;
     int src8 = 0; // pgx_set_source_format: 1 = the rgba arguments are 8-bit RGBA
 
     // status words: [0] sticky error bits

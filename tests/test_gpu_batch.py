@@ -174,7 +174,7 @@ def test_match_batch_more_pairs_than_one_chunk(engine):
     engine.set_match_chunk(128)
     d_out = _match_batch(engine, descs, sizes, pl, 400)
     engine.check_status()
-    engine.set_match_chunk(512)
+    engine.set_match_chunk(2048)
     out = d_out.cpu().numpy()
     for m, (a, b) in enumerate(pl):
         exp = cref.match_sorted(descs[a], descs[b])

@@ -168,7 +168,7 @@ def test_match_three_chunks_with_wide_rounds(engine):
     engine.profile_enable(True)
     engine.set_match_chunk(128)
     out = _match_dev(engine, descs, pl, 2560)
-    engine.set_match_chunk(512)
+    engine.set_match_chunk(2048)
     engine.profile_enable(False)
     n_wide, _ = engine.profile_get("ham_argmin")
     n_fin, _ = engine.profile_get("match_finish")

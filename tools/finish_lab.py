@@ -91,6 +91,16 @@ def main():
     eng.check_status()
     out = d_out.cpu().numpy()
     digest = hashlib.sha256(out.tobytes()).hexdigest()[:16]
+    # the stages in order on one stream, no profiling events
+    eng.profile_serialize(True)
+    match()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        match()
+    torch.cuda.synchronize()
+    ms_inorder = (time.perf_counter() - t0) * 1e3 / args.steps
+    eng.profile_serialize(False)
     if args.no_serial:
         print(json.dumps({"tag": args.tag, "pairs": M, "chunk": args.chunk or 256, "ms_pipelined": round(ms_pipe, 4), "sha": digest}), flush=True)
         eng.close()
@@ -118,7 +128,7 @@ def main():
     eng.check_status()
     digest2 = hashlib.sha256(d_out.cpu().numpy().tobytes()).hexdigest()[:16]
     res = {"tag": args.tag, "lib": os.path.basename(os.environ.get("PGX_LIB", "libpgx.so")), "pairs": M, "chunk": args.chunk or 256,
-           "ms_pipelined": round(ms_pipe, 4), "ms_serial": round(ms_serial, 4), "kernels_ms": kern, "sha": digest, "sha_serial": digest2,
+           "ms_pipelined": round(ms_pipe, 4), "ms_in_order": round(ms_inorder, 4), "ms_serial": round(ms_serial, 4), "kernels_ms": kern, "sha": digest, "sha_serial": digest2,
            "dbg_per_pair": [round(x, 2) for x in dbg], "dbg_per_pair_serial": [round(x, 2) for x in dbg_serial]}
     if args.check:
         from oracle import cref
