@@ -629,7 +629,8 @@ __device__ __forceinline__ uint8_t *tail_matrix(const PairWs &p)
 #include "k_match_tail.inc"
 #include "k_match_mfma.inc"
 
-size_t pgx_match_ws_bytes(int M, int stride) { return (size_t)M * pair_ws_words(stride) * 4; }
+// the M per-pair workspaces, then the order in which the per-pair finish takes the pairs (k_match_order)
+size_t pgx_match_ws_bytes(int M, int stride) { return ((size_t)M * pair_ws_words(stride) + (size_t)M) * 4; }
 
 template <int WORDS>
 static void launch_rounds_valu(hipStream_t s, uint32_t *ws, const uint32_t *desc, const int32_t *pairlist,
@@ -709,7 +710,9 @@ void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc
     if (plan.words == 8) {
         const size_t n2p = pow2_ge((size_t)(plan.max_n > 1 ? plan.max_n : 1));
         const size_t key_cap = n2p <= (size_t)4 * PGX_TAIL_MAX ? n2p : 0; // sort keys over the finish's own LDS state (32 KiB), else in the workspace
+        uint32_t *order = plan.M <= ORDER_MAX ? ws + (size_t)plan.M * pair_ws_words(plan.stride) : nullptr;
+        if (order) hipLaunchKernelGGL(k_match_order, dim3(1), dim3(1024), 0, s, ws, plan.stride, plan.M, order);
         hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(GS_NT), 0, s, ws, d_desc, d_pairlist, plan.stride, d_out,
-                           (uint32_t)key_cap, status);
+                           (uint32_t)key_cap, status, order);
     } else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out, status);
 }
