@@ -55,7 +55,7 @@ SEQ_FRAMES = 64
 MFMA_FP4 = True
 I8_MFMA_PEAK_OPS = 10.0e15   # name kept from round 1: operations of the 256-bit +-1 contraction per second (dense FP4 peak)
 HBM_PEAK = 8.0e12
-TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
 
 
 def log(*a):
@@ -78,14 +78,15 @@ def parse_args(argv=None):
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--no-standalone-pass", action="store_true",
                     help="skip the untimed pass that times every kernel with the matcher stages in order (under rocprofv3 --stats: "
-                         "every launch the profiler sees then ran in the pipelined mode the timed region measures)")
+                         "every launch the profiler sees then ran the way the timed region runs it)")
     ap.add_argument("--no-overlap-exchange", action="store_true",
                     help="N > 1: run the all-gather of the match lists synchronously at the end of every step (default: it is issued "
                          "asynchronously and awaited one step later, double-buffered; the last one is awaited inside the timed region)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="jobs kept in flight: consecutive steps alternate between this many contexts (each with its own streams and "
-                         "buffers), so one job's detect / exchanges run beside another job's match (measured on one GPU: 12.61 ms per step "
-                         "against 12.62 -- the matcher's own chunk pipeline already fills the chip); 1 = strictly one job at a time")
+                         "buffers), so one job's detect / exchanges run beside another job's match (measured on one GPU in round 4: 8.27 ms per step "
+                         "against 8.18 with one -- every stage of the matcher is bound by vector issue, a second job only gets in its way); "
+                         "1 = strictly one job at a time")
     ap.add_argument("--c-abi-comm", action="store_true",
                     help="N > 1: after the timed region, run the same job once more through the C ABI's own RCCL communicator "
                          "(pgx_comm_init + pgx_sequence_step_dev) and compare.  Off by default: it loads a second RCCL instance next to "
@@ -601,9 +602,9 @@ def worker(args):
                 ta = kern_alone["ham_argmin"]["ms_per_step"] * 1e-3
                 mfma["standalone"] = {"achieved": ops / ta / 1e12, "frac": ops / ta / I8_MFMA_PEAK_OPS,
                                       "ms_per_step": ta * 1e3,
-                                      "note": "the same steps with the matcher stages in order on one stream (pgx_profile_serialize): the kernel "
-                                              "alone on the chip; in the timed region it shares the chip with the residual-rows and per-pair "
-                                              "finish kernels of the neighbouring chunks, which stretches its event time"}
+                                      "note": "the same steps again, untimed, with every kernel group bracketed by events (pgx_profile_serialize).  Since "
+                                              "round 4 the timed region runs the matcher's stages in order too (one 2048-pair chunk at a time on "
+                                              "one stream), so the two figures measure the same thing and differ by run-to-run noise only"}
             rooflines["ham_argmin"] = mfma
         if detect_ms:
             byts = 24.0 * npix * F_l
@@ -639,10 +640,10 @@ def worker(args):
             "traffic_note": traffic_src,
             "rooflines": rooflines,
             "kernels": kern,
-            "kernels_note": "kernels: ham_argmin = HIP events over the TIMED steps (live: the matcher stages of consecutive chunks of 256 image "
-                            "pairs run side by side on three streams, so its bracket is stretched by the co-resident stages); every other "
-                            "group is taken from kernels_standalone (bracketing every launch costs 0.6 ms per step, so the timed region "
-                            "brackets the metric's kernel only).  kernels_standalone: the same steps again, untimed, stages in order on one stream",
+            "kernels_note": "kernels: ham_argmin = HIP events over the TIMED steps (live; the matcher's stages run in order, one chunk of "
+                            "<= 2048 image pairs at a time); every other group is taken from kernels_standalone (bracketing every launch "
+                            "costs 0.6 ms per step, so the timed region brackets the metric's kernel only).  kernels_standalone: the same "
+                            "steps again, untimed, every group bracketed",
             "kernels_standalone": kern_alone,
             "detect": {"ms_per_step": detect_ms, "frames_per_s": F_l / (detect_ms * 1e-3) if detect_ms else None},
             "match_only": {"ms_per_step_sum_of_kernels": match_ms,
