@@ -477,7 +477,8 @@ def worker(args):
         e.profile_filter(None)
         e.check_status()
         dbg = [a + b for a, b in zip(dbg, e.debug_counters())]
-    tail_rounds_per_pair = dbg[3] / float(max(1, args.steps * max(1, len(job.my_pairs))))
+    per_pair = float(max(1, args.steps * max(1, len(job.my_pairs))))
+    tail_scans_per_pair, tail_props_per_pair = dbg[4] / per_pair, dbg[6] / per_pair
     kern_timed = kernel_table(engs, args.steps) if rank == 0 else {}
     # stand-alone kernel times: in the timed region three matcher stages of consecutive chunks share the chip, so their
     # event brackets overlap and stretch each other; a second, untimed pass runs the same steps with the stages in order
@@ -495,7 +496,7 @@ def worker(args):
         eng.check_status()
         if rank == 0:
             kern_alone = kernel_table(eng, k_alone)
-    log('tail debug (rounds, row re-reads, re-read passes, proposals) per image pair:', [round(x / float(max(1, args.steps * max(1, len(job.my_pairs)))), 2) for x in dbg[3:7]])
+    log('finish (k_match_gs) per image pair: queue entries %.1f, matrix-row scans %.1f, proposals %.1f' % (dbg[3] / per_pair, tail_scans_per_pair, tail_props_per_pair))
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -650,7 +651,7 @@ def worker(args):
                            "wall_ms_per_step": max(step_ms - detect_ms, 0.0) if detect_ms else None,
                            "pairs_per_s": my_pairs_per_step / (max(step_ms - detect_ms, 1e-9) * 1e-3) if detect_ms else None,
                            "wide_rounds": rounds_wide, "evaluations_per_step": evals,
-                           "tail_rounds_per_image_pair": tail_rounds_per_pair,
+                           "finish_row_scans_per_image_pair": tail_scans_per_pair, "finish_proposals_per_image_pair": tail_props_per_pair,
                            "mfma_frac_of_peak_on_match_stage": (evals * 2.0 * P / (max(step_ms - detect_ms, 1e-9) * 1e-3)) / I8_MFMA_PEAK_OPS
                            if detect_ms else None,
                            "note": "match stage wall = step minus the detect kernels (rank 0); SURVEY 8d's match-only definition"},
