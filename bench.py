@@ -82,11 +82,16 @@ def parse_args(argv=None):
     ap.add_argument("--no-overlap-exchange", action="store_true",
                     help="N > 1: run the all-gather of the match lists synchronously at the end of every step (default: it is issued "
                          "asynchronously and awaited one step later, double-buffered; the last one is awaited inside the timed region)")
-    ap.add_argument("--in-flight", type=int, default=1,
-                    help="jobs kept in flight: consecutive steps alternate between this many contexts (each with its own streams and "
-                         "buffers), so one job's detect / exchanges run beside another job's match (measured on one GPU in round 4: 8.27 ms per step "
-                         "against 8.18 with one -- every stage of the matcher is bound by vector issue, a second job only gets in its way); "
-                         "1 = strictly one job at a time")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="jobs kept in flight: consecutive steps alternate between this many contexts (each with its own stream, buffers and "
+                         "workspaces); with 2 (default) the detect chain of step k + 1 runs beside the distance kernel of step k "
+                         "(round 4, same box: 7.43 ms per step against 8.04 with one job at a time); 1 = strictly one job at a time")
+    ap.add_argument("--gate", default="none,done",
+                    help="--in-flight >= 2: DETECT,MATCH = the stages of the previous job that a job's detect chain / matcher wait for "
+                         "(pgx_wait_stage; each one of none, detect, wide, rows, done).  Default none,done: the matcher of step k + 1 starts "
+                         "when step k's is done (the per-pair finish gains nothing from company, 1024-thread workgroups do not mix), its "
+                         "detect chain as soon as its stream gets to it, i.e. beside step k's distance kernel.  none,none: the GPU "
+                         "interleaves the jobs as it likes")
     ap.add_argument("--c-abi-comm", action="store_true",
                     help="N > 1: after the timed region, run the same job once more through the C ABI's own RCCL communicator "
                          "(pgx_comm_init + pgx_sequence_step_dev) and compare.  Off by default: it loads a second RCCL instance next to "
@@ -399,6 +404,9 @@ def worker(args):
     pairs = pg.make_brief_pairs(0, 50, P)
     dmap = None if args.no_dewarp else pg.build_dewarp_map(W, H, [3e-4, 1e-7, 0, 0, 0])
     NI = max(1, args.in_flight)
+    stage_of = {"none": None, "detect": 0, "wide": 1, "rows": 2, "done": 3}   # PGX_STAGE_*
+    GATES = tuple(stage_of[x] for x in args.gate.split(","))
+    assert len(GATES) == 2
     engs, jobs = [], []
     for k in range(NI):
         e = pg.Engine(local_rank)
@@ -416,7 +424,13 @@ def worker(args):
     step_no = [0]
 
     def run_step():
-        jobs[step_no[0] % NI].step(d_frames)
+        k = step_no[0] % NI
+        after = None
+        if NI > 1 and step_no[0] > 0:
+            # e.g. wide,none: job k's detect chain (memory- and cache-bound) beside the previous job's residual rows and
+            # per-pair finish (issue-bound), not beside its distance kernel (which it would only slow down)
+            after = (engs[(k - 1) % NI],) + GATES
+        jobs[k].step(d_frames, after=after)
         step_no[0] += 1
     # this rank's frames, made on the device: frame i of sequence s = base_s translated by (3i, i), wrap-around
     bases = {}
@@ -471,6 +485,8 @@ def worker(args):
         j.finish()   # the last steps' match-list exchanges belong to the timed region
     barrier()
     dt = time.perf_counter() - t0
+    for j in jobs[1:]:   # every context in flight computed the same job in the timed region: identical results (verify_job checks jobs[0])
+        assert torch.equal(j.out_all, job.out_all) and torch.equal(j.counts_all, job.counts_all) and torch.equal(j.desc_all, job.desc_all)
     dbg = [0] * 8
     for e in engs:
         e.profile_enable(False)
@@ -599,13 +615,16 @@ def worker(args):
                                    "chunk of image pairs, of which the spare one exits early on this workload; the residual R x C "
                                    "distances that k_tail_rows_fp4 evaluates once more are NOT counted)"
                                    % (evals, rounds_wide)}
+            if NI > 1:
+                mfma["note"] = ("two jobs in flight: the next step's detect chain runs beside this kernel on the same CUs, so its launch "
+                                "duration in the timed region includes that sharing (the step is shorter for it); `standalone` is the kernel "
+                                "with the chip to itself")
             if "ham_argmin" in kern_alone:
                 ta = kern_alone["ham_argmin"]["ms_per_step"] * 1e-3
                 mfma["standalone"] = {"achieved": ops / ta / 1e12, "frac": ops / ta / I8_MFMA_PEAK_OPS,
                                       "ms_per_step": ta * 1e3,
-                                      "note": "the same steps again, untimed, with every kernel group bracketed by events (pgx_profile_serialize).  Since "
-                                              "round 4 the timed region runs the matcher's stages in order too (one 2048-pair chunk at a time on "
-                                              "one stream), so the two figures measure the same thing and differ by run-to-run noise only"}
+                                      "note": "the same steps again, untimed, ONE job at a time, every kernel group bracketed by events "
+                                              "(pgx_profile_serialize)"}
             rooflines["ham_argmin"] = mfma
         if detect_ms:
             byts = 24.0 * npix * F_l
@@ -633,6 +652,8 @@ def worker(args):
                        "parallelism": "frames f mod %d, image pairs p mod %d; 2 all-gathers per step%s"
                                       % (world, world, "" if world > 1 else " (elided at N = 1)"),
                        "jobs_in_flight": NI,
+                       "stage_gates": None if NI < 2 else
+                       "step k+1 on the other context: detect chain waits for %s, matcher for %s of step k (pgx_wait_stage)" % tuple(args.gate.split(",")),
                        "rehearsal_on_one_gpu_with_gloo": rehearse},
             "roofline": rooflines.get(dominant),
             "verified": verified,

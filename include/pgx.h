@@ -166,6 +166,17 @@ int pgx_detect_batch_dev(pgx_ctx *ctx, const uint16_t *d_rgba64, int F, int W, i
 int pgx_match_batch_dev(pgx_ctx *ctx, const uint32_t *d_desc, const int32_t *d_counts,
                         int stride, int words, const int32_t *d_pairlist, int M, int max_count,
                         pgx_pair *d_out);
+/* Stage ordering between TWO contexts on one GPU (consecutive jobs kept in flight, each context on its own stream): `ctx`'s
+ * stream waits until stage `stage` of `other`'s most recent call of that kind has finished on the device (no wait if it has
+ * run none): PGX_STAGE_DETECT = the detect chain of pgx_detect_batch_dev; PGX_STAGE_MATCH_WIDE / _ROWS / _DONE = the whole-chip
+ * distance rounds / the residual distance rows / everything of pgx_match_batch_dev (the stages of pgx_sequence_step_dev count
+ * the same way).  Use: pgx_wait_stage(ctx, other, PGX_STAGE_MATCH_WIDE) before ctx's pgx_detect_batch_dev of job k + 1 places
+ * that detect chain -- bound by memory and cache requests -- beside job k's residual rows and per-pair finish -- bound by
+ * vector instruction issue -- instead of beside the distance kernel, which it would only slow down.  The reference has the
+ * same shape on the CPU: ApplyDistortionMat of image k + 1 runs beside Detect of image k (TestService.cs:25,146-149).
+ * Ordering only: results do not depend on it. */
+enum { PGX_STAGE_DETECT = 0, PGX_STAGE_MATCH_WIDE = 1, PGX_STAGE_MATCH_ROWS = 2, PGX_STAGE_MATCH_DONE = 3 };
+int pgx_wait_stage(pgx_ctx *ctx, pgx_ctx *other, int stage);
 
 /* ---- RANSAC fundamental matrix and camera pose, batched over image pairs (asynchronous, device pointers) --- */
 /* CameraPoseEstimation.GetFundamentalMatrix (CameraPoseEstimation.cs:26-94) for M image pairs at once: `keypointPairs` of

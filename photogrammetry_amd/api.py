@@ -139,6 +139,10 @@ class Engine:
     def set_match_chunk(self, image_pairs_per_chunk):
         self._chk(self._L.pgx_set_match_chunk(self._h, int(image_pairs_per_chunk)))
 
+    def wait_stage(self, other, stage):
+        """This context's stream waits for a stage (PGX_STAGE_*) of `other`'s most recent call of that kind (pgx.h)."""
+        self._chk(self._L.pgx_wait_stage(self._h, other._h, int(stage)))
+
     # -- stage-granular host API ----------------------------------------------------------
     def dewarp(self, rgba64):
         a = np.ascontiguousarray(rgba64, dtype=getattr(self, "_src_dtype", np.uint16))

@@ -171,9 +171,10 @@ __device__ __forceinline__ int clamp_n(const int32_t *n_raw_all, int f, int n_ca
     return n < 0 ? 0 : (n > n_cap ? n_cap : n);
 }
 
-// exclusive scan of one value per thread over the 1024-thread block; returns the block total
+// exclusive scan of one value per thread over the block (<= 1024 threads); returns the block total
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *excl, uint32_t *wsum /*[16]*/)
 {
+    const int nwv = (int)blockDim.x >> 6;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t incl = v;
 #pragma unroll
@@ -185,8 +186,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *excl, 
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
     uint32_t woff = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < NT / 64; w++) {
+    for (int w = 0; w < nwv; w++) {
         uint32_t s = wsum[w];
         if (w < wv) woff += s;
         total += s;
@@ -1293,12 +1293,14 @@ __device__ __forceinline__ bool tail_suppressed(const NmsPtrs &P, const NmsLayou
 }
 
 // Output order of a frame's accepted points (their keys were appended to P.sortkeys as they were accepted); called by the
-// whole 1024-thread workgroup of a tail kernel.
+// whole workgroup of a tail kernel (any multiple of 64 threads up to 1024); lds_cap = u64 keys the dynamic LDS holds.
 __device__ __forceinline__ void tail_order(const NmsPtrs &P, const NmsLayout &L, int radius, int n, const int32_t *raw_score,
                                            uint32_t *order, int32_t *n_kept_all, int f, int kp_cap, int kp_soft, int *status,
-                                           unsigned long long *lds_keys, uint32_t *wsum /*[16]*/, uint32_t *sh_cnt_p, int *sh_max_p)
+                                           unsigned long long *lds_keys, uint32_t lds_cap, uint32_t *wsum /*[16]*/, uint32_t *sh_cnt_p,
+                                           int *sh_max_p)
 {
     const int tid = threadIdx.x;
+    const int NT = (int)blockDim.x; // shadows the file's 1024: the mask-round tail runs with fewer threads
     uint32_t &sh_cnt = *sh_cnt_p;
     int &sh_max = *sh_max_p;
     // ---- the accepted points' keys (score descending, input index ascending) were appended as they were
@@ -1316,12 +1318,12 @@ __device__ __forceinline__ void tail_order(const NmsPtrs &P, const NmsLayout &L,
     const uint32_t nacc = sh_cnt;
     const uint32_t n2p = [](uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }(nacc > 1 ? nacc : 1);
     const uint32_t nw = ((uint32_t)n + 63u) / 64u * 2u;        // 32-bit bitmap words for the raster ranks of one score level
-    if (L.champ && radius >= 0 && nw <= SORT_LDS_MAX * 2) {
+    if (L.champ && radius >= 0 && nw <= lds_cap * 2) {
         // FAST scores are 12..16 and the input index is the raster rank, so the output order is "level by
         // level, rank ascending": one bitmap of ranks per level in LDS, a popcount scan, and every set bit
         // knows its place.  No comparison sort.
         uint32_t *bm = reinterpret_cast<uint32_t *>(lds_keys);
-        const uint32_t lp = (SORT_LDS_MAX * 2) / nw < 5u ? (SORT_LDS_MAX * 2) / nw : 5u; // levels per pass
+        const uint32_t lp = (lds_cap * 2) / nw < 5u ? (lds_cap * 2) / nw : 5u; // levels per pass
         const int lane = tid & 63, wv = tid >> 6;
         uint32_t base = 0;
         for (int lev_hi = 16; lev_hi >= 12; lev_hi -= (int)lp) {
@@ -1367,7 +1369,7 @@ __device__ __forceinline__ void tail_order(const NmsPtrs &P, const NmsLayout &L,
             }
             base += tot;
         }
-    } else if (n2p <= SORT_LDS_MAX) {
+    } else if (n2p <= lds_cap) {
         for (uint32_t i = tid; i < n2p; i += NT) lds_keys[i] = i < nacc ? P.sortkeys[i] : ~0ull;
         bitonic_sort_u64(lds_keys, n2p);
         for (uint32_t i = tid; i < nacc && i < (uint32_t)kp_cap; i += NT) order[i] = (uint32_t)lds_keys[i];
@@ -1521,21 +1523,28 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *raw_score_all,
         }
     }
 
-    tail_order(P, L, radius, n, raw_score, order, n_kept_all, f, kp_cap, kp_soft, status, lds_keys, wsum, &sh_cnt, &sh_max);
+    tail_order(P, L, radius, n, raw_score, order, n_kept_all, f, kp_cap, kp_soft, status, lds_keys, SORT_LDS_MAX, wsum, &sh_cnt, &sh_max);
 }
 
 // mask rounds continued by one workgroup per frame on a compact list of the cells whose champion entry is not zero yet
 // (open cells, plus closed ones that still have to take their stale entry down), a block barrier in place of the kernel
 // boundary; then the output order.
+// 256 threads and 64 KiB of LDS: one wave per SIMD at <= 128 registers, so that a workgroup finds room on a CU that still
+// runs a distance-kernel workgroup of another job (240 registers per wave, 35 KiB of LDS).  With 1024 threads x 121
+// registers and 128 KiB it needed a completely EMPTY CU, which never happens while the other job's distance kernel has
+// workgroups waiting: the whole detect chain of a second job in flight stalled here until that launch had drained (2.5 ms
+// instead of 0.1).  The rounds work on a few hundred listed cells, the order pass on 15 k bitmap words: alone it is as fast.
+constexpr int MT_NT = 512;
+constexpr uint32_t MT_SORT_LDS = 8192; // u64 keys -> 64 KiB
 template <int RR>
-__global__ __launch_bounds__(NT) void k_nmsm_tail(const int32_t *raw_score_all, const int32_t *__restrict__ n_raw_all, int n_cap,
+__global__ __launch_bounds__(MT_NT) void k_nmsm_tail(const int32_t *raw_score_all, const int32_t *__restrict__ n_raw_all, int n_cap,
                                                   NmsLayout L, int radius, unsigned char *ws_all, size_t ws_stride,
                                                   uint32_t *__restrict__ order_all, int32_t *__restrict__ n_kept_all, int kp_cap,
                                                   int *status, uint32_t *raw_xy_out, int32_t *raw_score_out, int kp_soft,
                                                   const unsigned long long *seg_all, const uint32_t *segoff_all, int H, int ntx)
 {
     extern __shared__ unsigned long long lds_keys[];
-    __shared__ uint32_t wsum[NT / 64];
+    __shared__ uint32_t wsum[MT_NT / 64];
     __shared__ uint32_t sh_cnt;
     __shared__ int sh_max;
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -1553,7 +1562,7 @@ __global__ __launch_bounds__(NT) void k_nmsm_tail(const int32_t *raw_score_all, 
                           segoff_all + (size_t)f * nseg, ntx};
         if (tid == 0) sh_cnt = 0;
         __syncthreads();
-        for (int c = tid; c < L.ncell; c += NT) {
+        for (int c = tid; c < L.ncell; c += MT_NT) {
             const int cy = c / L.gw, cx = c - cy * L.gw;
             if (M.ent[(cy + RR) * L.cgw + cx + RR] != 0u) M.listA[atomicAdd(&sh_cnt, 1u)] = (uint32_t)c;
         }
@@ -1564,7 +1573,7 @@ __global__ __launch_bounds__(NT) void k_nmsm_tail(const int32_t *raw_score_all, 
         int rounds = 0;
         __syncthreads();
         while (n_live > 0) {
-            for (int base = 0; base < n_live; base += NT) { // whole wavefronts: lane = one listed cell
+            for (int base = 0; base < n_live; base += MT_NT) { // whole wavefronts: lane = one listed cell
                 const int i = base + tid;
                 const bool in = i < n_live;
                 const int c = in ? (int)cur[i] : 0;
@@ -1572,7 +1581,7 @@ __global__ __launch_bounds__(NT) void k_nmsm_tail(const int32_t *raw_score_all, 
             }
             if (tid == 0) sh_cnt = 0;
             __syncthreads();
-            for (int i = tid; i < n_live; i += NT) {
+            for (int i = tid; i < n_live; i += MT_NT) {
                 const uint32_t c = cur[i];
                 const int cy = (int)c / L.gw, cx = (int)c - cy * L.gw;
                 if (M.ent[(cy + RR) * L.cgw + cx + RR] != 0u) nxt[atomicAdd(&sh_cnt, 1u)] = c; // order inside the list is irrelevant
@@ -1590,7 +1599,7 @@ __global__ __launch_bounds__(NT) void k_nmsm_tail(const int32_t *raw_score_all, 
     }
     __syncthreads();
     tail_order(P, L, radius, n, raw_score_all + (size_t)f * n_cap, order_all + (size_t)f * kp_cap, n_kept_all, f, kp_cap, kp_soft,
-               status, lds_keys, wsum, &sh_cnt, &sh_max);
+               status, lds_keys, MT_SORT_LDS, wsum, &sh_cnt, &sh_max);
 }
 
 } // namespace
@@ -1673,14 +1682,14 @@ void nms_finish(const NmsLaunch &a, int round0)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nms_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(SORT_LDS_MAX * 8));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nmsm_tail<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(SORT_LDS_MAX * 8));
+                                  (int)(MT_SORT_LDS * 8));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nmsm_tail<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(SORT_LDS_MAX * 8));
+                                  (int)(MT_SORT_LDS * 8));
         attr_set = true;
     }
     if (a.L.mask) {
         auto kern = a.L.R <= 2 ? &k_nmsm_tail<2> : &k_nmsm_tail<3>;
-        hipLaunchKernelGGL(kern, dim3(a.F), dim3(NT), SORT_LDS_MAX * 8, a.s, a.raw_score, a.n_raw, a.n_cap, a.L, a.radius, a.ws,
+        hipLaunchKernelGGL(kern, dim3(a.F), dim3(MT_NT), MT_SORT_LDS * 8, a.s, a.raw_score, a.n_raw, a.n_cap, a.L, a.radius, a.ws,
                            a.ws_stride, a.order, a.n_kept, a.kp_cap, a.status, a.raw_xy, a.raw_score, a.kp_soft, a.seg, a.segoff, a.H,
                            (a.W + 63) / 64);
         return;

@@ -137,6 +137,7 @@ int enqueue_detect(pgx_ctx *c, const uint16_t *d_rgba, int F, int W, int H, pgx_
                          c->ws_order.as<uint32_t>(), c->ws_nkept.as<int32_t>(), kp_eff, c->d_pairs.as<int32_t>(), c->P,
                          d_kp, d_desc, d_counts, cap);
     }
+    HIPCHK(c, hipEventRecord(c->ev_stage[PGX_STAGE_DETECT], c->stream));
     HIPCHK(c, hipGetLastError());
     return PGX_OK;
 }
@@ -177,6 +178,7 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     // its rounds, not by the residual's size), true-match sets unchanged.  From 8 pairs per call on the lower threshold costs
     // more than it saves on the frame sets (+6 %), and at full chunks +0.6 ms per bench step: those keep PGX_TAIL_MAX.
     if (words == 8 && M <= 2) plan.skip_below = PGX_TAIL_MAX / 2;
+    if (const char *e = getenv("PGX_SKIP_BELOW")) { const int v = atoi(e); if (v >= 64 && v <= PGX_TAIL_MAX && words == 8) plan.skip_below = v; } // developer A/B switch
     for (int n = plan.max_n; n > plan.skip_below && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
     if (plan.rounds_mfma > 0 && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS) plan.rounds_mfma++;
     HIPCHK(c, hipMemsetAsync(c->d_status + 4, 0, PGX_MAX_WIDE_ROUNDS * 8, c->stream));
@@ -189,7 +191,10 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
             plan.M = (M - m0 < CHUNK) ? M - m0 : CHUNK;
             const int32_t *pl = d_pairlist + 2 * (size_t)m0;
             pgx_launch_match_wide(c, c->stream, d_desc, d_counts, pl, plan, c->ws_matchn[0].p, c->d_status);
+            const bool last = m0 + CHUNK >= M; // pgx_wait_stage: the stages of the last chunk stand for the call
+            if (last) HIPCHK(c, hipEventRecord(c->ev_stage[PGX_STAGE_MATCH_WIDE], c->stream));
             pgx_launch_match_rows(c, c->stream, d_desc, pl, plan, c->ws_matchn[0].p, c->d_status);
+            if (last) HIPCHK(c, hipEventRecord(c->ev_stage[PGX_STAGE_MATCH_ROWS], c->stream));
             pgx_launch_match_finish(c, c->stream, d_desc, pl, plan, c->ws_matchn[0].p, d_out + (size_t)m0 * stride, c->d_status);
         }
     } else {
@@ -228,9 +233,11 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
             if (i >= NS) HIPCHK(c, hipStreamWaitEvent(sw, c->ev_fin[b], 0)); // this workspace's previous chunk is finished
             pgx_launch_match_wide(c, sw, d_desc, d_counts, pl, plan, ws, c->d_status);
             HIPCHK(c, hipEventRecord(c->ev_wide[b], sw));
+            if (m0 + CHUNK >= M) HIPCHK(c, hipEventRecord(c->ev_stage[PGX_STAGE_MATCH_WIDE], sw));
             HIPCHK(c, hipStreamWaitEvent(sr, c->ev_wide[b], 0));
             pgx_launch_match_rows(c, sr, d_desc, pl, plan, ws, c->d_status);
             HIPCHK(c, hipEventRecord(c->ev_rows[b], sr));
+            if (m0 + CHUNK >= M) HIPCHK(c, hipEventRecord(c->ev_stage[PGX_STAGE_MATCH_ROWS], sr));
             HIPCHK(c, hipStreamWaitEvent(sf, c->ev_rows[b], 0));
             pgx_launch_match_finish(c, sf, d_desc, pl, plan, ws, d_out + (size_t)m0 * stride, c->d_status);
             HIPCHK(c, hipEventRecord(c->ev_fin[b], sf));
@@ -241,6 +248,7 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
         }
     }
     c->last_rounds_mfma = plan.rounds_mfma;
+    HIPCHK(c, hipEventRecord(c->ev_stage[PGX_STAGE_MATCH_DONE], c->stream));
     HIPCHK(c, hipGetLastError());
     return PGX_OK;
 }
@@ -282,6 +290,10 @@ int pgx_ctx_create(int device, pgx_ctx **out)
     if (!c) return PGX_E_HIP;
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_stage[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_stage[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_stage[2], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_stage[3], hipEventDisableTiming) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->d_status), 256) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->h_status), 64, hipHostMallocDefault) != hipSuccess ||
         hipMemset(c->d_status, 0, 256) != hipSuccess) {
@@ -318,6 +330,7 @@ void pgx_ctx_destroy(pgx_ctx *c)
         if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
     }
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    for (int k = 0; k < 4; k++) if (c->ev_stage[k]) (void)hipEventDestroy(c->ev_stage[k]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -416,6 +429,20 @@ int pgx_set_match_chunk(pgx_ctx *c, int pairs)
     Lock l(c);
     if (pairs < 16 || pairs > 4096) return fail(c, PGX_E_BADARG, "image pairs per chunk must be in [16, 4096]");
     c->match_chunk = pairs;
+    return PGX_OK;
+}
+
+int pgx_wait_stage(pgx_ctx *c, pgx_ctx *other, int stage)
+{
+    if (!c || !other) return c ? fail(c, PGX_E_BADARG, "null context") : PGX_E_BADARG;
+    Lock l(c);
+    if (stage < 0 || stage > PGX_STAGE_MATCH_DONE) return fail(c, PGX_E_BADARG, "unknown stage %d", stage);
+    if (c == other) return PGX_OK; // a stream is in order with itself
+    if (c->device != other->device) return fail(c, PGX_E_BADARG, "contexts on different devices (%d, %d)", c->device, other->device);
+    // other->ev_stage[] are created with the context and never replaced: no lock on `other` (taking two context mutexes
+    // here could deadlock against a thread that calls the two contexts the other way round); an event that has not been
+    // recorded yet does not hold the stream
+    HIPCHK(c, hipStreamWaitEvent(c->stream, other->ev_stage[stage], 0));
     return PGX_OK;
 }
 

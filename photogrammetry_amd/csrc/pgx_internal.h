@@ -114,6 +114,10 @@ struct pgx_ctx {
     hipStream_t mstream[4] = {nullptr, nullptr, nullptr, nullptr}; // [0] wide rounds, [1] residual distance rows, [2], [3] per-pair finishes (alternating)
     hipEvent_t ev_in = nullptr, ev_wide[4] = {nullptr, nullptr, nullptr, nullptr}, ev_rows[4] = {nullptr, nullptr, nullptr, nullptr},
                ev_fin[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    // recorded behind the stages of the most recent calls (pgx_wait_stage: another context's work is held back until a stage
+    // of this one is done -- e.g. its detect chain until the distance rounds here are over, so that it runs beside the
+    // residual rows and the per-pair finish instead); [PGX_STAGE_*]
+    hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr};
 
     // multi-GPU: the RCCL communicator of this context's process (pgx_comm.hip); world 1 = none
     void *comm = nullptr;

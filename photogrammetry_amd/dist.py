@@ -225,10 +225,16 @@ class ShardedSequence:
         if self.on_gpu:
             engine.set_stream(self.stream.cuda_stream)
 
-    def step(self, d_frames_local):
-        """d_frames_local: uint16 [len(my_frames)][H][W][4] resident on this rank's GPU."""
+    def step(self, d_frames_local, after=None):
+        """d_frames_local: uint16 [len(my_frames)][H][W][4] resident on this rank's GPU.
+        after = (engine, detect_stage, match_stage): another job's engine on the same GPU (two jobs kept in flight, each on its
+        own stream) and the stages of ITS most recent step that this step's detect chain / matcher wait for (PGX_STAGE_* or
+        None; pgx_wait_stage).  Ordering only."""
         import contextlib
         nf, npr = len(self.my_frames), len(self.my_pairs)
+        other, gate_detect, gate_match = after if after is not None else (None, None, None)
+        if other is not None and gate_detect is not None and self.on_gpu:
+            self.e.wait_stage(other, gate_detect)
         if self.comm == "pgx":
             self.e.sequence_step_dev(d_frames_local, nf, self.fs, self.W, self.H, self.kp_l, self.desc_all, self.counts_all,
                                      self.nraw_l, self.nkp, self.pairlist_l, npr, self.ps, self.out_all)
@@ -264,6 +270,8 @@ class ShardedSequence:
             out_all = self.out_bufs[self._cur]
             lo_p = self.rank * self.ps
             out_l = out_all[lo_p:lo_p + self.ps]
+            if other is not None and gate_match is not None and self.on_gpu:
+                self.e.wait_stage(other, gate_match)
             if npr:
                 self.e.match_batch_dev(self.desc_all, self.counts_all, self.nkp, self.words, self.pairlist_l, npr,
                                        out_l, max_count=self.nkp)

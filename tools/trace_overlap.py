@@ -5,6 +5,7 @@ covered by every combination of kernel groups (developer tool).
   python tools/trace_overlap.py <kernel_trace.csv> [lo_frac hi_frac]
 """
 import csv
+import re
 import sys
 from collections import defaultdict
 
@@ -41,6 +42,13 @@ def main():
         ev.append((e2, -1, g))
         per[g][0] += 1
         per[g][1] += e2 - s2
+    byname = defaultdict(lambda: [0, 0.0])
+    for s, e, n in rows:
+        if s >= a and e <= b:
+            mm = re.search(r"k_\w+(<[^>]*>)?", n)
+            nm = mm.group(0) if mm else n[:60]
+            byname[nm][0] += 1
+            byname[nm][1] += e - s
     ev.sort()
     active = defaultdict(int)
     cover = defaultdict(float)
@@ -55,6 +63,9 @@ def main():
     print("window %.3f ms" % (span / 1e6))
     for k, v in sorted(cover.items(), key=lambda kv: -kv[1]):
         print("  %-28s %8.3f ms  %5.1f %%" % (k, v / 1e6, 100 * v / span))
+    print("per kernel (whole launches inside the window): launches, mean us, summed ms")
+    for n, (k, d) in sorted(byname.items(), key=lambda kv: -kv[1][1]):
+        print("  %-60s %6d %9.1f %9.3f" % (n, k, d / k / 1e3, d / 1e6))
     print("per group: launches, summed duration (ms), share of window")
     for g, (n, d) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         print("  %-8s %6d %9.3f  %5.1f %%" % (g, n, d / 1e6, 100 * d / span))
