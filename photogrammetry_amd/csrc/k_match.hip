@@ -260,6 +260,74 @@ __device__ void select_compact_wg(PairWs p, int parity, uint32_t *wsum)
     __syncthreads();
 }
 
+// The same for lists of at most PER * blockDim entries (every bench-sized round): a thread owns PER consecutive list places
+// through all phases and keeps what it loaded -- rows[r], the accept decision, cols[q], col_free -- in registers, so each phase
+// is ONE chain of dependent loads (list -> key -> partner's key; the general form above walks it three times: accept, count,
+// write) and the accept and row-compaction phases share theirs.  37 -> about 20 us per image pair of 4096 x 4096.
+template <int PER>
+__device__ void select_compact_wg_small(PairWs p, int parity, uint32_t *wsum)
+{
+    const int tid = threadIdx.x;
+    const int n1 = p.cnt[CNT_N1], n2 = p.cnt[CNT_N2];
+    const uint32_t *rows = (parity ? p.rows1 : p.rows0), *cols = (parity ? p.cols1 : p.cols0);
+    uint32_t *nrows = (parity ? p.rows0 : p.rows1), *ncols = (parity ? p.cols0 : p.cols1);
+    __syncthreads();
+    {   // accept (row i's best column j whose best row is i) and compact the rows that stay
+        uint32_t ii[PER], rk[PER], ck[PER];
+        bool in[PER], acc[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) { const int r = tid * PER + u; in[u] = r < n1; ii[u] = in[u] ? rows[r] : 0u; }
+#pragma unroll
+        for (int u = 0; u < PER; u++) rk[u] = in[u] ? p.rowkey[ii[u]] : PGX_KEY_NONE;
+#pragma unroll
+        for (int u = 0; u < PER; u++) ck[u] = rk[u] != PGX_KEY_NONE ? p.colkey[rk[u] & PGX_IDX_MASK] : PGX_KEY_NONE;
+        uint32_t c = 0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            acc[u] = rk[u] != PGX_KEY_NONE && ck[u] != PGX_KEY_NONE && (ck[u] & PGX_IDX_MASK) == ii[u];
+            if (acc[u]) {
+                p.mk2[ii[u]] = (int32_t)(rk[u] & PGX_IDX_MASK);
+                p.md[ii[u]] = (int32_t)(rk[u] >> PGX_IDX_BITS);
+                p.rowkey[ii[u]] = 0; // retired marker
+            }
+            c += (in[u] && !acc[u]) ? 1u : 0u;
+        }
+        uint32_t ex;
+        const uint32_t tot = block_excl_scan(c, &ex, wsum); // its barriers also publish mk2 to the column phase below
+        uint32_t o = ex;
+#pragma unroll
+        for (int u = 0; u < PER; u++)
+            if (in[u] && !acc[u]) { nrows[o++] = ii[u]; p.rowkey[ii[u]] = PGX_KEY_NONE; }
+        if (tid == 0) { p.cnt[CNT_NACC] += n1 - (int)tot; p.cnt[CNT_N1] = (int)tot; }
+    }
+    __syncthreads();
+    {   // a column retires iff its best row accepted it (then that row's mk2 points back at it)
+        uint32_t jj[PER], ck[PER];
+        int32_t mk[PER];
+        bool in[PER], fr[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) { const int q = tid * PER + u; in[u] = q < n2; jj[u] = in[u] ? cols[q] : 0u; }
+#pragma unroll
+        for (int u = 0; u < PER; u++) ck[u] = in[u] ? p.colkey[jj[u]] : PGX_KEY_NONE;
+#pragma unroll
+        for (int u = 0; u < PER; u++) mk[u] = ck[u] != PGX_KEY_NONE ? p.mk2[ck[u] & PGX_IDX_MASK] : -1;
+        uint32_t c = 0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            fr[u] = in[u] && (ck[u] == PGX_KEY_NONE || mk[u] != (int32_t)jj[u]);
+            c += fr[u] ? 1u : 0u;
+        }
+        uint32_t ex;
+        const uint32_t tot = block_excl_scan(c, &ex, wsum); // every thread has evaluated its columns before anyone resets a key
+        uint32_t o = ex;
+#pragma unroll
+        for (int u = 0; u < PER; u++)
+            if (fr[u]) { ncols[o++] = jj[u]; p.colkey[jj[u]] = PGX_KEY_NONE; }
+        if (tid == 0) { p.cnt[CNT_N2] = (int)tot; p.cnt[CNT_PARITY] = parity ^ 1; }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(SEL_NT) void k_match_select(uint32_t *ws, int S, unsigned long long *evals, int skip_below)
 {
     __shared__ uint32_t wsum[SEL_NT / 64];
@@ -268,7 +336,9 @@ __global__ __launch_bounds__(SEL_NT) void k_match_select(uint32_t *ws, int S, un
     if (p.cnt[CNT_N1] <= skip_below && p.cnt[CNT_N2] <= skip_below) return; // round was skipped
     const int parity = p.cnt[CNT_PARITY];
     if (threadIdx.x == 0) atomicAdd(evals, (unsigned long long)p.cnt[CNT_N1] * (unsigned long long)p.cnt[CNT_N2]);
-    select_compact_wg(p, parity, wsum);
+    const int nmax = p.cnt[CNT_N1] > p.cnt[CNT_N2] ? p.cnt[CNT_N1] : p.cnt[CNT_N2]; // read before the barrier inside: thread 0 rewrites the counts at the end
+    if (nmax <= 4 * SEL_NT) select_compact_wg_small<4>(p, parity, wsum);
+    else select_compact_wg(p, parity, wsum);
 }
 
 // bitonic sort of `n2p` (power of two) u32 keys, ascending, by the whole workgroup.  The sort is bound by LDS traffic

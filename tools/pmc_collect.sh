@@ -7,7 +7,8 @@ OUT=$(realpath -m "${1:-gpurun_out/r02_pmc}")
 REPO=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --no-extra-configs --no-cpu-baseline --steps 3 --warmup 1"
+# counter passes: one job at a time (the profiler serialises dispatches anyway; per-kernel attribution stays clean)
+BENCH="python3 $REPO/bench.py --no-extra-configs --no-cpu-baseline --steps 3 --warmup 1 --in-flight 1"
 WANT=" ${PASSES:-stats fetch write tcp tcc ta sq mfma} "
 want() { [[ "$WANT" == *" $1 "* ]]; }
 if want stats; then
