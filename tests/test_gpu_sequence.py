@@ -439,3 +439,68 @@ def test_match_sizes_beyond_the_bench(engine, n1, n2, kind):
     assert (got["k1"] == exp["k1"]).all() and (got["k2"] == exp["k2"]).all() and (got["dist"] == exp["dist"]).all()
     if n1 > n2:
         assert int((got["dist"] == pg.api.PGX_DIST_NONE).sum()) == n1 - n2
+
+
+@pytest.mark.parametrize("gates", [(None, 3), (1, None), (2, 3), (0, 1)])
+def test_two_jobs_in_flight_with_stage_gates_equal_one_job(engine, gates):
+    """bench.py's default form: two contexts, two streams, consecutive steps alternate between them and pgx_wait_stage orders
+    a step's detect chain / matcher behind stages of the previous step on the OTHER context (PGX_STAGE_*: 0 detect, 1 match
+    wide, 2 match rows, 3 match done).  Ordering only: every step of either context must equal the one-job result, whatever
+    the gates; frames differ between steps so that a step reading the other context's buffers would show."""
+    W, H, NKP, radius, F = 640, 480, 1024, 12, 6
+    pairs = pg.make_brief_pairs(0, 50, 256)
+    pl = pdist.all_pairs(F)
+    base = synth.make_frame(W, H, seed=99, n_shapes=3000)
+    d_base = torch.from_numpy(base).to(DEV)
+
+    def frames_of(step):
+        d = torch.empty((F, H, W, 4), dtype=torch.uint16, device=DEV)
+        for i in range(F):
+            d.view(torch.int64)[i] = torch.roll(d_base.view(torch.int64), shifts=((i + 5 * step) % H, (3 * i + 7 * step) % W), dims=(0, 1))
+        return d
+
+    def configure(e):
+        e.set_brief_pairs(pairs)
+        e.set_detect_params(T, radius)
+        e.set_capacity(1 << 16, NKP)
+        e.set_dewarp_map(None)
+
+    nsteps = 6
+    inputs = [frames_of(s) for s in range(nsteps)]
+    torch.cuda.synchronize()
+    configure(engine)
+    ref_job = pdist.ShardedSequence(engine, W, H, F, pl, NKP, 8, DEV, stream=torch.cuda.Stream(device=DEV))
+    ref = []
+    for s in range(nsteps):
+        ref_job.step(inputs[s])
+        torch.cuda.synchronize()
+        engine.check_status()
+        ref.append((ref_job.out_all.clone(), ref_job.counts_all.clone(), ref_job.desc_all.clone()))
+    assert int(ref[0][1].min()) > 50
+    engs = [pg.Engine(0), pg.Engine(0)]
+    try:
+        jobs = []
+        for e in engs:
+            configure(e)
+            jobs.append(pdist.ShardedSequence(e, W, H, F, pl, NKP, 8, DEV, stream=torch.cuda.Stream(device=DEV)))
+        got = []
+        for s in range(nsteps):   # nothing synchronises between the steps: results are copied on the job's own stream
+            k = s % 2
+            jobs[k].step(inputs[s], after=(engs[1 - k],) + tuple(gates) if s > 0 else None)
+            with torch.cuda.stream(jobs[k].stream):
+                got.append((jobs[k].out_all.clone(), jobs[k].counts_all.clone(), jobs[k].desc_all.clone()))
+        torch.cuda.synchronize()
+        for e in engs:
+            e.check_status()
+        for s in range(nsteps):
+            for a, b in zip(got[s], ref[s]):
+                assert torch.equal(a, b), "step %d differs from the one-job result" % s
+        # argument checks of the new entry point
+        with pytest.raises(pg.ArgumentException):
+            engs[0].wait_stage(engs[1], 4)
+        with pytest.raises(pg.ArgumentException):
+            engs[0].wait_stage(engs[1], -1)
+        engs[0].wait_stage(engs[0], 1)   # a context and itself: a stream is in order with itself
+    finally:
+        for e in engs:
+            e.close()
