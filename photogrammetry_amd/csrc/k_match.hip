@@ -782,7 +782,7 @@ void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc
         const size_t key_cap = n2p <= (size_t)4 * PGX_TAIL_MAX ? n2p : 0; // sort keys over the finish's own LDS state (32 KiB), else in the workspace
         uint32_t *order = plan.M <= ORDER_MAX ? ws + (size_t)plan.M * pair_ws_words(plan.stride) : nullptr;
         if (order) hipLaunchKernelGGL(k_match_order, dim3(1), dim3(1024), 0, s, ws, plan.stride, plan.M, order);
-        hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(GS_NT), 0, s, ws, d_desc, d_pairlist, plan.stride, d_out,
+        hipLaunchKernelGGL(k_match_gs, dim3(plan.M), dim3(plan.M >= GS_SMALL_FROM ? GS_NT : GS_NT_MAX), 0, s, ws, d_desc, d_pairlist, plan.stride, d_out,
                            (uint32_t)key_cap, status, order);
     } else launch_finish<0>(s, ws, d_desc, d_pairlist, plan, d_out, status);
 }
