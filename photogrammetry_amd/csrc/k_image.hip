@@ -203,7 +203,13 @@ void pgx_launch_dewarp_gray(hipStream_t s, const void *rgba, int src8, const int
     if (F <= 0 || W <= 0 || H <= 0) return;
     const size_t ngroups = ((size_t)W * H + 3) / 4;
     unsigned gx = (unsigned)((ngroups + 255) / 256);
-    if (gx > 4096u) gx = 4096u; // >> 256 CUs, grid-stride beyond
+    // About 512 workgroups per launch (two per CU), grid-stride beyond: a streaming kernel needs that many to keep HBM busy and
+    // no more -- with one workgroup per 1024 pixels (32 400 of them for 64 frames of 1920x1080) the launch was 5 % slower alone,
+    // and beside another job's distance kernel the flood of small workgroups took every wave slot that came free (two jobs in
+    // flight: 7.19 -> 7.12 ms per bench step with the bounded grid).
+    const unsigned ny = (unsigned)((F + FB - 1) / FB);
+    const unsigned cap = 512u / ny > 32u ? 512u / ny : 32u;
+    if (gx > cap) gx = cap;
     dim3 grid(gx, (unsigned)((F + FB - 1) / FB)), block(256);
     const int2 *map = reinterpret_cast<const int2 *>(map_uv);
     uint2 *dw = reinterpret_cast<uint2 *>(dewarped);
