@@ -504,3 +504,25 @@ def test_two_jobs_in_flight_with_stage_gates_equal_one_job(engine, gates):
     finally:
         for e in engs:
             e.close()
+
+
+def test_match_many_pairs_with_sets_above_4096(engine):
+    """561 image pairs in ONE launch (>= 512: the per-pair finish runs its 512-thread form) over 34 descriptor sets of
+    4200-4700 entries (above the 4096 of the counting emit: the closing sort is the bitonic one over the finish's own LDS),
+    tie-heavy like the three-chunk test; pairs spread over the launch against the oracle."""
+    rng = np.random.default_rng(77)
+    F = 34
+    sizes = [int(x) for x in rng.integers(4200, 4700, F)]
+    base = rng.integers(0, 2**32, (5200, 8), dtype=np.uint32)
+    descs = []
+    for f in range(F):
+        d = base[rng.permutation(5200)[:sizes[f]]].copy()
+        d[:, 2] ^= rng.integers(0, 8, sizes[f]).astype(np.uint32)
+        descs.append(d)
+    pl = [(a, b) for a in range(F) for b in range(a + 1, F)]
+    assert len(pl) == 561
+    engine.set_match_chunk(2048)
+    out = _match_dev(engine, descs, pl, 4736)
+    for m in (0, 1, 255, 256, 511, 512, 560):
+        a, b = pl[m]
+        assert _same(out[m][:sizes[a]], cref.match_sorted(descs[a], descs[b])), (a, b)
