@@ -177,6 +177,11 @@ int pgx_match_batch_dev(pgx_ctx *ctx, const uint32_t *d_desc, const int32_t *d_c
  * Ordering only: results do not depend on it. */
 enum { PGX_STAGE_DETECT = 0, PGX_STAGE_MATCH_WIDE = 1, PGX_STAGE_MATCH_ROWS = 2, PGX_STAGE_MATCH_DONE = 3 };
 int pgx_wait_stage(pgx_ctx *ctx, pgx_ctx *other, int stage);
+/* The same wait, placed INSIDE ctx's next matcher call (pgx_match_batch_dev / pgx_sequence_step_dev; one shot): between its
+ * init kernel -- which touches ctx's own workspace only and so runs ahead, beside whatever `other` still has on the chip -- and
+ * its first whole-chip distance round, which then starts the moment the gate opens (with pgx_wait_stage in front of the call the
+ * init kernel sits on the critical path: 0.2 ms per step of the bench job).  `other` must outlive that call. */
+int pgx_gate_match(pgx_ctx *ctx, pgx_ctx *other, int stage);
 
 /* ---- RANSAC fundamental matrix and camera pose, batched over image pairs (asynchronous, device pointers) --- */
 /* CameraPoseEstimation.GetFundamentalMatrix (CameraPoseEstimation.cs:26-94) for M image pairs at once: `keypointPairs` of

@@ -30,6 +30,7 @@ internal static unsafe class PgxNative
     [DllImport(Lib)] public static extern int pgx_set_capacity(IntPtr ctx, int maxRaw, int maxKeypoints);
     [DllImport(Lib)] public static extern int pgx_set_source_format(IntPtr ctx, int format); // 0 = Rgba64, 1 = Rgba32 bytes (widened x257 on the device)
     [DllImport(Lib)] public static extern int pgx_set_match_chunk(IntPtr ctx, int imagePairsPerChunk);
+    [DllImport(Lib)] public static extern int pgx_gate_match(IntPtr ctx, IntPtr other, int stage);  // the same wait inside the next matcher call, behind its init kernel
     [DllImport(Lib)] public static extern int pgx_wait_stage(IntPtr ctx, IntPtr other, int stage);   // PGX_STAGE_*: 0 detect, 1 match wide, 2 match rows, 3 match done
     [DllImport(Lib)] public static extern int pgx_dewarp(IntPtr ctx, ushort* rgba64, int w, int h, ushort* outRgba64);
     [DllImport(Lib)] public static extern int pgx_gray(IntPtr ctx, ushort* rgba64, int w, int h, float* outGray);

@@ -24,7 +24,7 @@ EXPORTS = [
     "pgx_check_status", "pgx_set_dewarp_map", "pgx_set_dewarp_coeffs", "pgx_get_dewarp_map", "pgx_set_brief_pairs",
     "pgx_set_detect_params",
     "pgx_set_capacity", "pgx_set_source_format", "pgx_set_match_chunk", "pgx_dewarp", "pgx_gray", "pgx_fast", "pgx_brief", "pgx_nms", "pgx_match", "pgx_match_batch",
-    "pgx_detect", "pgx_detect_batch_dev", "pgx_match_batch_dev", "pgx_wait_stage", "pgx_profile_enable",
+    "pgx_detect", "pgx_detect_batch_dev", "pgx_match_batch_dev", "pgx_wait_stage", "pgx_gate_match", "pgx_profile_enable",
     "pgx_profile_get", "pgx_profile_filter", "pgx_profile_reset", "pgx_profile_serialize", "pgx_match_stats", "pgx_debug_counters", "pgx_make_brief_pairs",
     "pgx_build_dewarp_map", "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_info",
     "pgx_allgather_dev", "pgx_sequence_step_dev", "pgx_tracks_create", "pgx_tracks_destroy", "pgx_tracks_add_pair",

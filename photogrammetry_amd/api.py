@@ -143,6 +143,11 @@ class Engine:
         """This context's stream waits for a stage (PGX_STAGE_*) of `other`'s most recent call of that kind (pgx.h)."""
         self._chk(self._L.pgx_wait_stage(self._h, other._h, int(stage)))
 
+    def gate_match(self, other, stage):
+        """The next matcher call of this context waits for a stage of `other` between its init kernel and its first distance
+        round (pgx_gate_match; one shot)."""
+        self._chk(self._L.pgx_gate_match(self._h, other._h, int(stage)))
+
     # -- stage-granular host API ----------------------------------------------------------
     def dewarp(self, rgba64):
         a = np.ascontiguousarray(rgba64, dtype=getattr(self, "_src_dtype", np.uint16))

@@ -735,7 +735,7 @@ static void launch_finish(hipStream_t s, uint32_t *ws, const uint32_t *desc, con
 }
 
 void pgx_launch_match_wide(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_counts,
-                           const int32_t *d_pairlist, const MatchPlan &plan, void *wsv, int *status)
+                           const int32_t *d_pairlist, const MatchPlan &plan, void *wsv, int *status, hipEvent_t gate)
 {
     if (plan.M <= 0) return;
     uint32_t *ws = reinterpret_cast<uint32_t *>(wsv);
@@ -744,6 +744,9 @@ void pgx_launch_match_wide(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, 
         hipLaunchKernelGGL(k_match_init, dim3((plan.stride + 255) / 256 > 64 ? 64 : (plan.stride + 255) / 256, plan.M),
                            dim3(256), 0, s, ws, d_counts, d_pairlist, plan.stride, plan.max_n, status);
     }
+    // pgx_gate_match: the init kernel touches this context's workspace only, so it runs ahead of the gate (beside whatever the
+    // other context still has on the chip) and the first distance round starts the moment the gate opens
+    if (gate) (void)hipStreamWaitEvent(s, gate, 0);
     for (int r = 0; r < plan.rounds_mfma; r++) {
         {
             if (plan.words == 8) {   // 256-bit descriptors: the matrix pipe

@@ -186,11 +186,13 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     // stage of the matcher is bound by vector-instruction issue, so running the stages of consecutive chunks side by side
     // buys nothing (round 4: 6.43 ms side by side against 6.25 in order at 1024 pairs per chunk), while a large chunk gives
     // the per-pair finish several workgroups per CU to balance (2016 pairs in one chunk: 6.0 ms).
+    hipEvent_t gate = c->match_gate; // one shot (pgx_gate_match)
+    c->match_gate = nullptr;
     if (M <= CHUNK || c->prof_serial || CHUNK >= PGX_PIPELINE_BELOW) { // everything in order on the context's stream
         for (int m0 = 0; m0 < M; m0 += CHUNK) {
             plan.M = (M - m0 < CHUNK) ? M - m0 : CHUNK;
             const int32_t *pl = d_pairlist + 2 * (size_t)m0;
-            pgx_launch_match_wide(c, c->stream, d_desc, d_counts, pl, plan, c->ws_matchn[0].p, c->d_status);
+            pgx_launch_match_wide(c, c->stream, d_desc, d_counts, pl, plan, c->ws_matchn[0].p, c->d_status, m0 == 0 ? gate : nullptr);
             const bool last = m0 + CHUNK >= M; // pgx_wait_stage: the stages of the last chunk stand for the call
             if (last) HIPCHK(c, hipEventRecord(c->ev_stage[PGX_STAGE_MATCH_WIDE], c->stream));
             pgx_launch_match_rows(c, c->stream, d_desc, pl, plan, c->ws_matchn[0].p, c->d_status);
@@ -221,6 +223,7 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
         }
         if (!c->ev_in) HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
         hipStream_t sw = c->mstream[0], sr = c->mstream[1];
+        if (gate) HIPCHK(c, hipStreamWaitEvent(c->stream, gate, 0)); // the three-stream form takes the gate in front of everything
         HIPCHK(c, hipEventRecord(c->ev_in, c->stream));
         for (int k = 0; k < NS; k++) HIPCHK(c, hipStreamWaitEvent(c->mstream[k], c->ev_in, 0));
         int i = 0;
@@ -443,6 +446,16 @@ int pgx_wait_stage(pgx_ctx *c, pgx_ctx *other, int stage)
     // here could deadlock against a thread that calls the two contexts the other way round); an event that has not been
     // recorded yet does not hold the stream
     HIPCHK(c, hipStreamWaitEvent(c->stream, other->ev_stage[stage], 0));
+    return PGX_OK;
+}
+
+int pgx_gate_match(pgx_ctx *c, pgx_ctx *other, int stage)
+{
+    if (!c || !other) return c ? fail(c, PGX_E_BADARG, "null context") : PGX_E_BADARG;
+    Lock l(c);
+    if (stage < 0 || stage > PGX_STAGE_MATCH_DONE) return fail(c, PGX_E_BADARG, "unknown stage %d", stage);
+    if (c->device != other->device) return fail(c, PGX_E_BADARG, "contexts on different devices (%d, %d)", c->device, other->device);
+    c->match_gate = c == other ? nullptr : other->ev_stage[stage]; // events live as long as their context (see pgx_wait_stage)
     return PGX_OK;
 }
 

@@ -118,6 +118,8 @@ struct pgx_ctx {
     // of this one is done -- e.g. its detect chain until the distance rounds here are over, so that it runs beside the
     // residual rows and the per-pair finish instead); [PGX_STAGE_*]
     hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    // pgx_gate_match: the next matcher call waits for this event between its init kernel and its first distance round (one shot)
+    hipEvent_t match_gate = nullptr;
 
     // multi-GPU: the RCCL communicator of this context's process (pgx_comm.hip); world 1 = none
     void *comm = nullptr;
@@ -254,8 +256,9 @@ struct MatchPlan {
 size_t pgx_match_ws_bytes(int M, int stride);
 // the three stages of one chunk of image pairs -- wide part (init, whole-chip mutual-nearest rounds), residual distance
 // rows (256-bit descriptors only), per-pair finish; they may run on different streams (the caller orders them with events)
+// gate: an event the stream waits for between the init kernel and the first distance round (or nullptr)
 void pgx_launch_match_wide(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_counts,
-                           const int32_t *d_pairlist, const MatchPlan &plan, void *ws, int *status);
+                           const int32_t *d_pairlist, const MatchPlan &plan, void *ws, int *status, hipEvent_t gate = nullptr);
 void pgx_launch_match_rows(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_pairlist,
                            const MatchPlan &plan, void *ws, int *status);
 void pgx_launch_match_finish(pgx_ctx *ctx, hipStream_t s, const uint32_t *d_desc, const int32_t *d_pairlist,

@@ -236,6 +236,8 @@ class ShardedSequence:
         if other is not None and gate_detect is not None and self.on_gpu:
             self.e.wait_stage(other, gate_detect)
         if self.comm == "pgx":
+            if other is not None and gate_match is not None and self.on_gpu:
+                self.e.gate_match(other, gate_match)
             self.e.sequence_step_dev(d_frames_local, nf, self.fs, self.W, self.H, self.kp_l, self.desc_all, self.counts_all,
                                      self.nraw_l, self.nkp, self.pairlist_l, npr, self.ps, self.out_all)
             return
@@ -271,7 +273,7 @@ class ShardedSequence:
             lo_p = self.rank * self.ps
             out_l = out_all[lo_p:lo_p + self.ps]
             if other is not None and gate_match is not None and self.on_gpu:
-                self.e.wait_stage(other, gate_match)
+                self.e.gate_match(other, gate_match)   # inside the matcher call, behind its init kernel
             if npr:
                 self.e.match_batch_dev(self.desc_all, self.counts_all, self.nkp, self.words, self.pairlist_l, npr,
                                        out_l, max_count=self.nkp)
