@@ -662,10 +662,11 @@ def worker(args):
             "traffic_note": traffic_src,
             "rooflines": rooflines,
             "kernels": kern,
-            "kernels_note": "kernels: ham_argmin = HIP events over the TIMED steps (live; the matcher's stages run in order, one chunk of "
-                            "<= 2048 image pairs at a time); every other group is taken from kernels_standalone (bracketing every launch "
-                            "costs 0.6 ms per step, so the timed region brackets the metric's kernel only).  kernels_standalone: the same "
-                            "steps again, untimed, every group bracketed",
+            "kernels_note": "kernels: ham_argmin = HIP events over the TIMED steps (live; a job's matcher stages run in order, one chunk of "
+                            "<= 2048 image pairs at a time, and with two jobs in flight the other job's detect chain runs beside this "
+                            "kernel); every other group is taken from kernels_standalone (bracketing every launch costs 0.6 ms per step, so "
+                            "the timed region brackets the metric's kernel only).  kernels_standalone: the same steps again, untimed, one "
+                            "job at a time, every group bracketed -- their sum exceeds ms_per_step by what the two jobs overlap",
             "kernels_standalone": kern_alone,
             "detect": {"ms_per_step": detect_ms, "frames_per_s": F_l / (detect_ms * 1e-3) if detect_ms else None},
             "match_only": {"ms_per_step_sum_of_kernels": match_ms,
