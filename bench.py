@@ -421,17 +421,28 @@ def worker(args):
                                           overlap_exchange=not args.no_overlap_exchange))
     eng, job = engs[0], jobs[0]
     stream = job.stream
-    step_no = [0]
 
-    def run_step():
-        k = step_no[0] % NI
-        after = None
-        if NI > 1 and step_no[0] > 0:
-            # e.g. wide,none: job k's detect chain (memory- and cache-bound) beside the previous job's residual rows and
-            # per-pair finish (issue-bound), not beside its distance kernel (which it would only slow down)
-            after = (engs[(k - 1) % NI],) + GATES
-        jobs[k].step(d_frames, after=after)
-        step_no[0] += 1
+    def run_steps(n):
+        """n whole steps.  With two or more jobs in flight the halves of consecutive steps are issued interleaved -- front(s + 1)
+        (detect + descriptor gather) before back(s) (match + list gather): the GPU work of a job stays in order on its own
+        stream either way, but on the communicator, whose collectives run in issue order, the next step's small descriptor
+        gather then stands in FRONT of this step's large list gather (N > 1: the next matcher never waits for 792 MB of lists
+        to cross the links).  Exactly n fronts and n backs are issued; at N = 1 there is no collective and the order of issue
+        changes nothing on the device."""
+        def gates(s):
+            # step s runs on job s % NI; its gates refer to the previous step's job.  Default none,done: the matcher of step s
+            # starts when step s - 1's is done, its detect chain as soon as its stream gets to it (beside that distance kernel)
+            return (engs[(s - 1) % NI],) + GATES if (NI > 1 and s > 0) else None
+        if NI == 1 or GATES[0] is not None:   # a detect gate names a stage of the PREVIOUS step's matcher call: keep whole steps in order
+            for s in range(n):
+                jobs[s % NI].step(d_frames, after=gates(s))
+            return
+        jobs[0].front(d_frames, gates(0))
+        for s in range(n):
+            if s + 1 < n:
+                jobs[(s + 1) % NI].front(d_frames, gates(s + 1))
+            jobs[s % NI].back(gates(s))
+
     # this rank's frames, made on the device: frame i of sequence s = base_s translated by (3i, i), wrap-around
     bases = {}
     with torch.cuda.stream(stream):
@@ -453,8 +464,7 @@ def worker(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(NI, args.warmup)):
-        run_step()
+    run_steps(max(NI, args.warmup))
     for j in jobs:
         j.finish()
     torch.cuda.synchronize()
@@ -476,11 +486,9 @@ def worker(args):
         e.profile_filter("ham_argmin")
         e.profile_enable(not args.no_profile)
         e.debug_counters()   # clears them
-    step_no[0] = 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
+    run_steps(args.steps)
     for j in jobs:
         j.finish()   # the last steps' match-list exchanges belong to the timed region
     barrier()

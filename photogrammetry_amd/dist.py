@@ -229,18 +229,33 @@ class ShardedSequence:
         """d_frames_local: uint16 [len(my_frames)][H][W][4] resident on this rank's GPU.
         after = (engine, detect_stage, match_stage): another job's engine on the same GPU (two jobs kept in flight, each on its
         own stream) and the stages of ITS most recent step that this step's detect chain / matcher wait for (PGX_STAGE_* or
-        None; pgx_wait_stage).  Ordering only."""
-        import contextlib
-        nf, npr = len(self.my_frames), len(self.my_pairs)
-        other, gate_detect, gate_match = after if after is not None else (None, None, None)
-        if other is not None and gate_detect is not None and self.on_gpu:
-            self.e.wait_stage(other, gate_detect)
-        if self.comm == "pgx":
-            if other is not None and gate_match is not None and self.on_gpu:
-                self.e.gate_match(other, gate_match)
+        None; pgx_wait_stage / pgx_gate_match).  Ordering only.
+        step = front + back.  A caller that keeps two jobs in flight on G > 1 ranks issues the halves interleaved --
+        front(s + 1) BEFORE back(s) -- so that on the communicator (whose collectives run in issue order) the small descriptor
+        gather of step s + 1 stands in front of the large match-list gather of step s instead of behind it: the matcher of step
+        s + 1 then never waits for step s's lists to cross the links (792 MB per step at 8 GPUs)."""
+        if self.comm == "pgx":   # ONE C call does all four phases
+            nf, npr = len(self.my_frames), len(self.my_pairs)
+            other, gate_detect, gate_match = after if after is not None else (None, None, None)
+            if other is not None and self.on_gpu:
+                if gate_detect is not None:
+                    self.e.wait_stage(other, gate_detect)
+                if gate_match is not None:
+                    self.e.gate_match(other, gate_match)
             self.e.sequence_step_dev(d_frames_local, nf, self.fs, self.W, self.H, self.kp_l, self.desc_all, self.counts_all,
                                      self.nraw_l, self.nkp, self.pairlist_l, npr, self.ps, self.out_all)
             return
+        self.front(d_frames_local, after)
+        self.back(after)
+
+    def front(self, d_frames_local, after=None):
+        """Phases 1 and 2: detect this rank's frames, gather the descriptor records (comm = "torch")."""
+        import contextlib
+        assert self.comm == "torch"
+        nf = len(self.my_frames)
+        other, gate_detect, _ = after if after is not None else (None, None, None)
+        if other is not None and gate_detect is not None and self.on_gpu:
+            self.e.wait_stage(other, gate_detect)
         with (torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()):
             # A rank whose local part fails before the first collective (not configured, a size mismatch, no memory for a
             # workspace: all of them properties of the configuration, raised by the first call) must not leave its peers
@@ -269,6 +284,14 @@ class ShardedSequence:
             if self.world > 1:
                 dist.all_gather_into_tensor(self.desc_all, self.desc_l, group=self.group)
                 dist.all_gather_into_tensor(self.counts_all, self.counts_l, group=self.group)
+
+    def back(self, after=None):
+        """Phases 3 and 4: match this rank's image pairs, gather the match lists (comm = "torch")."""
+        import contextlib
+        assert self.comm == "torch"
+        npr = len(self.my_pairs)
+        other, _, gate_match = after if after is not None else (None, None, None)
+        with (torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()):
             out_all = self.out_bufs[self._cur]
             lo_p = self.rank * self.ps
             out_l = out_all[lo_p:lo_p + self.ps]

@@ -219,6 +219,58 @@ def test_sharded_sequence_equals_single_process(world, overlap):
         assert (m == matches).all(), rank
 
 
+def _interleaved_worker(rank, world, port, q):
+    """Two jobs in flight the way bench.py issues them: front(s + 1) before back(s), overlapped list exchange."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pairs = cref.gaussian_pairs(0, 20, 256)
+        fr = _frames()
+        pl = pdist.all_pairs(N_FRAMES)
+        jobs = [pdist.ShardedSequence(_OracleEngine(pairs), W, H, N_FRAMES, pl, CAP, 8, "cpu", overlap_exchange=True) for _ in range(2)]
+        mine = torch.from_numpy(np.stack([fr[f] for f in jobs[0].my_frames]))
+        n = 5
+        jobs[0].front(mine)
+        for s in range(n):
+            if s + 1 < n:
+                jobs[(s + 1) % 2].front(mine)
+            jobs[s % 2].back()
+        for j in jobs:
+            j.finish()
+        res = []
+        for j in jobs:
+            res.append((np.stack([j.descriptors(f).numpy() for f in range(N_FRAMES)]), j.counts(),
+                        np.stack([j.matches(p).numpy() for p in range(len(pl))])))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_jobs_with_interleaved_halves_equal_single_process(world):
+    """front(s + 1) is issued before back(s) (bench.py with two jobs in flight: on the communicator the next step's descriptor
+    gather then stands in front of this step's list gather); every rank issues the same sequence of collectives, and both
+    jobs must end with the single-process result."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_interleaved_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    desc, counts, pl, matches = _single_process()
+    for rank, res in results:
+        for d, c, m in res:
+            assert (c == counts).all(), rank
+            assert (d == desc).all(), rank
+            assert (m == matches).all(), rank
+
+
 def test_slot_of_is_a_bijection():
     for world in (1, 2, 3, 8):
         for n in (1, 5, 64, 2016):
