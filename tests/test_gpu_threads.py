@@ -14,6 +14,13 @@ from photogrammetry_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+try:   # torch ships its own HIP runtime: it has to see the GPU before libpgx's does, or torch finds no device afterwards
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+except Exception:  # noqa: BLE001 -- the tests that need torch say so themselves
+    pass
+
 W, H, T, RADIUS, CAP = 640, 360, np.float32(0.1), 12, 4096
 COEFFS = [3e-4, 1e-7, 0, 0, 0]
 N_FRAMES = 6
@@ -164,3 +171,77 @@ def test_last_error_is_per_thread():
         assert got and ("dewarp map" in got[0] or "keypoints2 is empty" in got[0]), got
     finally:
         e.close()
+
+
+def test_two_threads_two_contexts_with_stage_gates():
+    """Two host threads, each driving its own context and stream through device-resident jobs (pgx_detect_batch_dev, then
+    pgx_match_batch_dev behind pgx_gate_match / pgx_wait_stage on the OTHER thread's context): the gates read the other
+    context's stage events while that thread records them.  Whatever the interleaving, every step of either thread must
+    equal the result of the same job run alone."""
+    import torch
+    from photogrammetry_amd import dist as pdist
+    DEV = "cuda:0"
+    Wt, Ht, NKP, F = 640, 480, 1024, 5
+    pairs = pg.make_brief_pairs(0, 50, 256)
+    pl = pdist.all_pairs(F)
+    base = torch.from_numpy(synth.make_frame(Wt, Ht, seed=7, n_shapes=3000)).to(DEV)
+
+    def frames_of(tag, step):
+        d = torch.empty((F, Ht, Wt, 4), dtype=torch.uint16, device=DEV)
+        for i in range(F):
+            d.view(torch.int64)[i] = torch.roll(base.view(torch.int64), shifts=((i + 3 * step + 11 * tag) % Ht, (3 * i + 5 * step) % Wt), dims=(0, 1))
+        return d
+
+    def configure(e):
+        e.set_brief_pairs(pairs)
+        e.set_detect_params(T, RADIUS)
+        e.set_capacity(1 << 16, NKP)
+        e.set_dewarp_map(None)
+
+    nsteps = 8
+    inputs = {(tag, s): frames_of(tag, s) for tag in (0, 1) for s in range(nsteps)}
+    torch.cuda.synchronize()
+    ref_e = pg.Engine(0)
+    engs = [pg.Engine(0), pg.Engine(0)]
+    try:
+        configure(ref_e)
+        ref_job = pdist.ShardedSequence(ref_e, Wt, Ht, F, pl, NKP, 8, DEV, stream=torch.cuda.Stream(device=DEV))
+        ref = {}
+        for key, fr in inputs.items():
+            ref_job.step(fr)
+            torch.cuda.synchronize()
+            ref_e.check_status()
+            ref[key] = (ref_job.out_all.clone(), ref_job.counts_all.clone())
+        jobs = []
+        for e in engs:
+            configure(e)
+            jobs.append(pdist.ShardedSequence(e, Wt, Ht, F, pl, NKP, 8, DEV, stream=torch.cuda.Stream(device=DEV)))
+        got, errors = {}, []
+        start = threading.Barrier(2)
+
+        def drive(tag):
+            try:
+                torch.cuda.set_device(0)
+                start.wait()
+                for s in range(nsteps):
+                    gates = (engs[1 - tag], 1 if s % 2 else None, 3)   # detect behind the other's wide rounds on odd steps, matcher behind its last matcher
+                    jobs[tag].step(inputs[(tag, s)], after=gates)
+                    with torch.cuda.stream(jobs[tag].stream):
+                        got[(tag, s)] = (jobs[tag].out_all.clone(), jobs[tag].counts_all.clone())
+            except Exception as ex:  # noqa: BLE001
+                errors.append((tag, ex))
+
+        th = [threading.Thread(target=drive, args=(t,)) for t in (0, 1)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        assert not errors, errors
+        torch.cuda.synchronize()
+        for e in engs:
+            e.check_status()
+        for key in inputs:
+            assert torch.equal(got[key][0], ref[key][0]) and torch.equal(got[key][1], ref[key][1]), key
+    finally:
+        for e in engs + [ref_e]:
+            e.close()
