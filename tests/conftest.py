@@ -13,6 +13,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch ships its own HIP runtime next to the system one libpgx.so links: torch's has to see the GPU first, or torch finds
+    # "No HIP GPUs" once a pgx context exists.  On a GPU box, initialise it before any test creates a context (whatever subset
+    # of the tests is run); without a GPU this does nothing.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # noqa: BLE001 -- the tests that need torch say so themselves
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -14,13 +14,6 @@ from photogrammetry_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-try:   # torch ships its own HIP runtime: it has to see the GPU before libpgx's does, or torch finds no device afterwards
-    import torch
-    if torch.cuda.is_available():
-        torch.cuda.init()
-except Exception:  # noqa: BLE001 -- the tests that need torch say so themselves
-    pass
-
 W, H, T, RADIUS, CAP = 640, 360, np.float32(0.1), 12, 4096
 COEFFS = [3e-4, 1e-7, 0, 0, 0]
 N_FRAMES = 6
