@@ -441,13 +441,14 @@ def test_match_sizes_beyond_the_bench(engine, n1, n2, kind):
         assert int((got["dist"] == pg.api.PGX_DIST_NONE).sum()) == n1 - n2
 
 
-@pytest.mark.parametrize("gates", [(None, 3), (1, None), (2, 3), (0, 1)])
-def test_two_jobs_in_flight_with_stage_gates_equal_one_job(engine, gates):
+@pytest.mark.parametrize("gates,chunk", [((None, 3), 2048), ((1, None), 2048), ((2, 3), 2048), ((0, 1), 2048), ((None, 3), 16), ((1, 2), 16)])
+def test_two_jobs_in_flight_with_stage_gates_equal_one_job(engine, gates, chunk):
     """bench.py's default form: two contexts, two streams, consecutive steps alternate between them and pgx_wait_stage orders
     a step's detect chain / matcher behind stages of the previous step on the OTHER context (PGX_STAGE_*: 0 detect, 1 match
     wide, 2 match rows, 3 match done).  Ordering only: every step of either context must equal the one-job result, whatever
-    the gates; frames differ between steps so that a step reading the other context's buffers would show."""
-    W, H, NKP, radius, F = 640, 480, 1024, 12, 6
+    the gates; frames differ between steps so that a step reading the other context's buffers would show.  chunk = 16: the 21
+    image pairs go through in two workspace chunks on the library's three streams (the gate then sits in front of everything)."""
+    W, H, NKP, radius, F = 640, 480, 1024, 12, 7
     pairs = pg.make_brief_pairs(0, 50, 256)
     pl = pdist.all_pairs(F)
     base = synth.make_frame(W, H, seed=99, n_shapes=3000)
@@ -482,6 +483,7 @@ def test_two_jobs_in_flight_with_stage_gates_equal_one_job(engine, gates):
         jobs = []
         for e in engs:
             configure(e)
+            e.set_match_chunk(chunk)
             jobs.append(pdist.ShardedSequence(e, W, H, F, pl, NKP, 8, DEV, stream=torch.cuda.Stream(device=DEV)))
         got = []
         for s in range(nsteps):   # nothing synchronises between the steps: results are copied on the job's own stream
