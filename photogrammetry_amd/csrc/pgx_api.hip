@@ -178,7 +178,6 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     // its rounds, not by the residual's size), true-match sets unchanged.  From 8 pairs per call on the lower threshold costs
     // more than it saves on the frame sets (+6 %), and at full chunks +0.6 ms per bench step: those keep PGX_TAIL_MAX.
     if (words == 8 && M <= 2) plan.skip_below = PGX_TAIL_MAX / 2;
-    if (const char *e = getenv("PGX_SKIP_BELOW")) { const int v = atoi(e); if (v >= 64 && v <= PGX_TAIL_MAX && words == 8) plan.skip_below = v; } // developer A/B switch
     for (int n = plan.max_n; n > plan.skip_below && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS; n = (n + 1) / 2) plan.rounds_mfma++;
     if (plan.rounds_mfma > 0 && plan.rounds_mfma < PGX_MAX_WIDE_ROUNDS) plan.rounds_mfma++;
     HIPCHK(c, hipMemsetAsync(c->d_status + 4, 0, PGX_MAX_WIDE_ROUNDS * 8, c->stream));
