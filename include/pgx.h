@@ -237,18 +237,46 @@ int pgx_sequence_step_dev(pgx_ctx *ctx, const uint16_t *d_frames_local, int n_lo
                           int capacity, const int32_t *d_pairlist_local, int n_local_pairs, int pair_slots,
                           pgx_pair *d_out_all);
 
-/* ---- the track graph over the gathered match lists (host side, no GPU work) ------------------------- */
-/* Not in the reference.  Union-find over (frame, keypoint) nodes: a match of image pair (a, b) links
- * (a, k1) with (b, k2) when dist <= max_dist; a union that would put two keypoints of ONE frame into a track is refused
- * (first come, in list order).  counts [n_frames] = keypoints per frame. */
+/* ---- the track graph over the gathered match lists -------------------------------------------------- */
+/* Not in the reference (TestService.cs:80-96 handles one image pair); north_star names it as the consumer of the
+ * gathered lists.  What the reference does hold is the distance gate: python_src/scripts/match_keypoints.py:23,127
+ * (`--match-threshold`), `new KeypointMatching(100)` in the commented code of Photogrammetry/Program.cs:165,224.
+ * Semantics -- order-independent, so the device build and the sequential host build below give the same result bit for bit:
+ *   nodes   (frame, keypoint) with keypoint < counts[frame]
+ *   edges   entry e < counts[a] of image pair (a, b)'s list links (a, k1) with (b, k2) when dist <= max_dist; the
+ *           (0, 0, PGX_DIST_NONE) tail entries (KeypointMatching.cs:40-42) never link, whatever max_dist is
+ *   tracks  connected components with at least min_len nodes; a component that holds two keypoints of ONE frame is
+ *           inconsistent and dropped as a whole (counted, its nodes marked -2)
+ *   order   tracks by their first (frame, keypoint), nodes inside a track ascending.
+ *
+ * Device form (asynchronous on the context's stream, device pointers): the lists are used where the matcher / the all-gather
+ * left them.  d_matches [M][stride], d_counts [F], d_pairlist [M][2] exactly as for pgx_match_batch_dev (pair m's frames are
+ * SLOT indices into d_counts).  d_frame_ids [F] (or NULL = identity, n_frames = F) maps a slot to the frame NUMBER the graph
+ * uses, in [0, n_frames), distinct; -1 = this slot is not part of the graph (padding slots of the rank-major gathered buffers;
+ * frames of sequences another rank builds the graph for): image pairs that touch such a slot are skipped.  Outputs:
+ *   d_track_of [n_frames][stride]   track index of every node; -1 = no track (beyond counts, or a component below min_len),
+ *                                   -2 = dropped with its inconsistent component
+ *   d_offsets  [n_frames*stride+1]  the first n_tracks + 1 entries: track t's nodes are d_nodes[d_offsets[t] .. d_offsets[t+1])
+ *   d_nodes    [n_frames*stride][2] (frame, keypoint)
+ *   d_summary  [8]                  n_tracks, n_nodes, dropped components, nodes in them, edges used, longest track,
+ *                                   largest dropped component, 0
+ * n_frames * stride <= 2^30.  min_len < 1 counts as 1. */
+int pgx_tracks_dev(pgx_ctx *ctx, const pgx_pair *d_matches, const int32_t *d_counts, const int32_t *d_pairlist, int M, int F,
+                   int stride, const int32_t *d_frame_ids, int n_frames, int max_dist, int min_len,
+                   int32_t *d_track_of, int32_t *d_offsets, int32_t *d_nodes, int32_t *d_summary);
+
+/* Host form, no GPU work (small inputs; a host that holds the lists in managed memory): the same semantics, sequential.
+ * counts [n_frames] = keypoints per frame. */
 typedef struct pgx_tracks pgx_tracks;
 int  pgx_tracks_create(const int32_t *counts, int n_frames, pgx_tracks **out);
 void pgx_tracks_destroy(pgx_tracks *t);
-/* matches: the first n entries of one image pair's list (n = counts[frame_a]); PGX_DIST_NONE tail entries never link. */
+/* matches: the first n entries of one image pair's list (n = counts[frame_a]). */
 int  pgx_tracks_add_pair(pgx_tracks *t, int frame_a, int frame_b, const pgx_pair *matches, int n, int max_dist);
-/* Tracks with at least min_len nodes, ordered by their first (frame, keypoint); nodes inside a track ascending. */
+/* Closes the graph: *n_tracks consistent components of at least min_len nodes with *n_nodes nodes in all. */
 int  pgx_tracks_finish(pgx_tracks *t, int min_len, int *n_tracks, int *n_nodes);
 int  pgx_tracks_get(pgx_tracks *t, int32_t *track_offsets /* [n_tracks + 1] */, int32_t *nodes /* [n_nodes][2] = (frame, keypoint) */);
+/* After pgx_tracks_finish: inconsistent components and the nodes in them (what d_summary[2], [3] report on the device). */
+int  pgx_tracks_dropped(pgx_tracks *t, int *n_components, int *n_nodes);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------- */
 /* When on, the named hot kernels are bracketed by HIP events on the launch stream. */

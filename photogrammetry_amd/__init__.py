@@ -5,8 +5,8 @@ the C ABI in include/pgx.h); this package is the thin host-side mirror used by t
 """
 from .api import (ArgumentException, ArgumentOutOfRangeException, CapacityError, DeWarp, Engine, Grayscale,
                   IndexOutOfRangeException, KEYPOINT_DTYPE, KeypointDetection, KeypointMatching, PAIR_DTYPE,
-                  PgxError, RcclError, RedundantKeypointEliminator, build_dewarp_map, comm_unique_id, make_brief_pairs)
+                  PgxError, RcclError, RedundantKeypointEliminator, build_dewarp_map, comm_unique_id, make_brief_pairs, tracks_host)
 
 __all__ = ["ArgumentException", "ArgumentOutOfRangeException", "CapacityError", "DeWarp", "Engine", "Grayscale",
            "IndexOutOfRangeException", "KEYPOINT_DTYPE", "KeypointDetection", "KeypointMatching", "PAIR_DTYPE",
-           "PgxError", "RcclError", "RedundantKeypointEliminator", "build_dewarp_map", "comm_unique_id", "make_brief_pairs"]
+           "PgxError", "RcclError", "RedundantKeypointEliminator", "build_dewarp_map", "comm_unique_id", "make_brief_pairs", "tracks_host"]

@@ -28,7 +28,7 @@ EXPORTS = [
     "pgx_profile_get", "pgx_profile_filter", "pgx_profile_reset", "pgx_profile_serialize", "pgx_match_stats", "pgx_debug_counters", "pgx_make_brief_pairs",
     "pgx_build_dewarp_map", "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_info",
     "pgx_allgather_dev", "pgx_sequence_step_dev", "pgx_tracks_create", "pgx_tracks_destroy", "pgx_tracks_add_pair",
-    "pgx_tracks_finish", "pgx_tracks_get", "pgx_fundamental_ransac_dev", "pgx_pose_dev",
+    "pgx_tracks_finish", "pgx_tracks_get", "pgx_tracks_dropped", "pgx_tracks_dev", "pgx_fundamental_ransac_dev", "pgx_pose_dev",
 ]
 
 

@@ -247,6 +247,15 @@ class Engine:
                                        int(stride), _dptr(d_F), _dptr(d_Rt), _dptr(d_votes), _dptr(d_best),
                                        _dptr(d_points) if d_points is not None else None))
 
+    # -- the track graph on the device (pgx_tracks_dev) ----------------------------------------------
+    def tracks_dev(self, d_matches, d_counts, d_pairlist, M, F, stride, n_frames, max_dist, min_len, d_track_of, d_offsets,
+                   d_nodes, d_summary, d_frame_ids=None):
+        """Connected components over the gated match lists where they sit in HBM (pgx.h: order-independent semantics).
+        d_track_of [n_frames][stride], d_offsets [n_frames * stride + 1], d_nodes [n_frames * stride][2], d_summary [8]."""
+        self._chk(self._L.pgx_tracks_dev(self._h, _dptr(d_matches), _dptr(d_counts), _dptr(d_pairlist), int(M), int(F), int(stride),
+                                         _dptr(d_frame_ids) if d_frame_ids is not None else None, int(n_frames), int(max_dist),
+                                         int(min_len), _dptr(d_track_of), _dptr(d_offsets), _dptr(d_nodes), _dptr(d_summary)))
+
     # -- multi-GPU: the context's own RCCL communicator (pgx_comm_*) ------------------------------
     def comm_init(self, rank, world, unique_id):
         """Collective: every rank calls this with the 128 bytes rank 0 got from comm_unique_id()."""
@@ -309,6 +318,35 @@ def comm_unique_id():
     if rc != PGX_OK:
         raise PgxError(rc, "pgx_comm_unique_id: librccl could not be loaded or ncclGetUniqueId failed")
     return bytes(buf)
+
+
+def tracks_host(counts, pair_list, lists, max_dist, min_len=2):
+    """The host form of the track graph (pgx_tracks_*: sequential, no GPU work; same semantics as Engine.tracks_dev).
+    counts [F]; pair_list [(a, b)]; lists[m] = that pair's match list ([n][3] ints or PAIR_DTYPE).
+    -> (tracks, dropped_components, dropped_nodes); tracks = list of [(frame, keypoint)] lists in pgx_tracks_get's order."""
+    L = _lib.lib()
+    c = np.ascontiguousarray(counts, dtype=np.int32)
+    h = C.c_void_p()
+    if L.pgx_tracks_create(_ptr(c), len(c), C.byref(h)) != PGX_OK:
+        raise PgxError(PGX_E_BADARG, "pgx_tracks_create")
+    try:
+        for (a, b), rows in zip(pair_list, lists):
+            rows = np.asarray(rows)
+            if rows.dtype == PAIR_DTYPE:
+                rows = np.stack([rows["k1"], rows["k2"], rows["dist"]], axis=1)
+            rows = np.ascontiguousarray(rows.reshape(-1, 3)[:int(c[a])], dtype=np.int32)
+            if L.pgx_tracks_add_pair(h, int(a), int(b), _ptr(rows), len(rows), int(max_dist)) != PGX_OK:
+                raise PgxError(PGX_E_BADARG, "pgx_tracks_add_pair(%d, %d)" % (a, b))
+        nt, nn, nd, ndn = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        if L.pgx_tracks_finish(h, int(min_len), C.byref(nt), C.byref(nn)) != PGX_OK:
+            raise PgxError(PGX_E_BADARG, "pgx_tracks_finish")
+        off = np.zeros(nt.value + 1, dtype=np.int32)
+        nodes = np.zeros((max(nn.value, 1), 2), dtype=np.int32)
+        if L.pgx_tracks_get(h, _ptr(off), _ptr(nodes)) != PGX_OK or L.pgx_tracks_dropped(h, C.byref(nd), C.byref(ndn)) != PGX_OK:
+            raise PgxError(PGX_E_BADARG, "pgx_tracks_get")
+        return [[(int(f), int(k)) for f, k in nodes[off[t]:off[t + 1]]] for t in range(nt.value)], nd.value, ndn.value
+    finally:
+        L.pgx_tracks_destroy(h)
 
 
 def make_brief_pairs(seed, sigma, P):

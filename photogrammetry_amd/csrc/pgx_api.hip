@@ -318,7 +318,7 @@ void pgx_ctx_destroy(pgx_ctx *c)
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
     DevBuf *bufs[] = {&c->d_pairs, &c->d_map, &c->ws_gray, &c->ws_seg, &c->ws_segoff, &c->ws_nraw, &c->ws_rawxy,
                       &c->ws_rawscore, &c->ws_nms, &c->ws_order, &c->ws_nkept, &c->st_a, &c->st_b, &c->st_c,
-                      &c->st_d, &c->st_e, &c->st_f, &c->ws_pose, &c->ws_matchn[0], &c->ws_matchn[1], &c->ws_matchn[2], &c->ws_matchn[3]};
+                      &c->st_d, &c->st_e, &c->st_f, &c->ws_pose, &c->ws_tracks, &c->ws_agree, &c->ws_matchn[0], &c->ws_matchn[1], &c->ws_matchn[2], &c->ws_matchn[3]};
     for (DevBuf *b : bufs) b->release();
     c->pin_in.release();
     c->pin_out.release();
@@ -775,6 +775,30 @@ int pgx_pose_dev(pgx_ctx *c, const pgx_keypoint *d_kp, const pgx_pair *d_matches
         return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
     Lock l(c);
     pgx_launch_pose(c->stream, d_kp, d_matches, d_counts, d_pairlist, M, stride, d_F, d_Rt, d_votes, d_best, d_points);
+    HIPCHK(c, hipGetLastError());
+    return PGX_OK;
+}
+
+// ---- the track graph on the device ---------------------------------------------------------------
+
+int pgx_tracks_dev(pgx_ctx *c, const pgx_pair *d_matches, const int32_t *d_counts, const int32_t *d_pairlist, int M, int F,
+                   int stride, const int32_t *d_frame_ids, int n_frames, int max_dist, int min_len, int32_t *d_track_of,
+                   int32_t *d_offsets, int32_t *d_nodes, int32_t *d_summary)
+{
+    if (!c || !d_counts || !d_track_of || !d_offsets || !d_nodes || !d_summary || M < 0 || (M > 0 && (!d_matches || !d_pairlist)))
+        return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
+    Lock l(c);
+    if (F <= 0 || stride <= 0 || n_frames <= 0) return fail(c, PGX_E_BADARG, "F, stride and n_frames must be positive");
+    if (!d_frame_ids && n_frames != F) return fail(c, PGX_E_BADARG, "without d_frame_ids, n_frames must equal F");
+    if ((long long)n_frames * stride > (1ll << 30)) return fail(c, PGX_E_BADARG, "n_frames * stride must be <= 2^30");
+    if ((long long)M * ((stride + 255) / 256) > 0x7FFFFFFFll || (long long)F * ((stride + 255) / 256) > 0x7FFFFFFFll)
+        return fail(c, PGX_E_BADARG, "too many image pairs for one call");
+    HIPCHK(c, c->ws_tracks.ensure(pgx_tracks_ws_bytes(n_frames, stride)));
+    {
+        ProfScope ps(c, "tracks");
+        pgx_launch_tracks(c->stream, d_matches, d_counts, d_pairlist, M, F, stride, d_frame_ids, n_frames, max_dist, min_len,
+                          c->ws_tracks.p, d_track_of, d_offsets, d_nodes, d_summary);
+    }
     HIPCHK(c, hipGetLastError());
     return PGX_OK;
 }

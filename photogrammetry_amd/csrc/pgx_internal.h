@@ -110,7 +110,7 @@ struct pgx_ctx {
     PinBuf pin_in, pin_out; // pgx_match_batch
     // match workspaces: four, so that with several chunks of image pairs the stages of consecutive chunks run side by side
     DevBuf ws_matchn[4];
-    DevBuf ws_pose;
+    DevBuf ws_pose, ws_tracks;
     hipStream_t mstream[4] = {nullptr, nullptr, nullptr, nullptr}; // [0] wide rounds, [1] residual distance rows, [2], [3] per-pair finishes (alternating)
     hipEvent_t ev_in = nullptr, ev_wide[4] = {nullptr, nullptr, nullptr, nullptr}, ev_rows[4] = {nullptr, nullptr, nullptr, nullptr},
                ev_fin[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -243,6 +243,12 @@ void pgx_launch_fundamental(hipStream_t s, const pgx_keypoint *kp, const pgx_pai
 void pgx_launch_pose(hipStream_t s, const pgx_keypoint *kp, const pgx_pair *matches, const int32_t *counts,
                      const int32_t *pairlist, int M, int stride, const float *F_in, float *Rt_out, int32_t *votes,
                      int32_t *best, float *points);
+
+// k_tracks.hip
+size_t pgx_tracks_ws_bytes(int n_frames, int stride);
+void pgx_launch_tracks(hipStream_t s, const pgx_pair *d_matches, const int32_t *d_counts, const int32_t *d_pairlist, int M, int F,
+                       int stride, const int32_t *d_frame_ids, int n_frames, int max_dist, int min_len, void *ws,
+                       int32_t *d_track_of, int32_t *d_offsets, int32_t *d_nodes, int32_t *d_summary);
 
 // k_match.hip
 struct MatchPlan {

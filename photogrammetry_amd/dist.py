@@ -10,8 +10,8 @@ it couples image pairs, so the path shards with no data-path collective inside d
   phase 4  exchange    ONE all-gather of the match lists; fixed size because the reference always
                        emits exactly N1 entries per image pair (KeypointMatching.cs:38)
 
-The gathered lists feed the track graph (union-find over (frame, keypoint) nodes), which the
-reference does not have and which lives on the host.
+The gathered lists feed the track graph (connected components over (frame, keypoint) nodes; the reference
+does not have one), built on the device where the lists sit: pgx_tracks_dev, `ShardedSequence(tracks=...)`.
 Only tensors cross this module; it never touches the oracle.
 """
 import numpy as np
@@ -72,85 +72,14 @@ def exchange_matches(out_local, n_pairs):
     return all_gather_slots(out_local, n_pairs)
 
 
-class TrackGraph:
-    """Union-find over (frame, keypoint) nodes fed by the gathered match lists.  A match (k1, k2,
-    dist) of image pair (a, b) links node (a, k1) with (b, k2) when dist <= max_dist (the distance
-    gate the live C# matcher lacks).  Tracks that would contain two keypoints of the
-    same frame are split by refusing the offending union (first come, in list order)."""
-
-    def __init__(self, counts):
-        self.counts = [int(c) for c in counts]
-        self.base = np.concatenate([[0], np.cumsum(self.counts)]).astype(np.int64)
-        n = int(self.base[-1])
-        self.parent = np.arange(n, dtype=np.int64)
-        self.frames = [{int(f)} for f, c in enumerate(self.counts) for _ in range(c)]
-
-    def node(self, frame, k):
-        return int(self.base[frame] + k)
-
-    def find(self, x):
-        p = self.parent
-        while p[x] != x:
-            p[x] = p[p[x]]
-            x = p[x]
-        return int(x)
-
-    def add_pair(self, a, b, matches, max_dist):
-        """matches: [N1][3] (k1, k2, dist) for frames (a, b)."""
-        for k1, k2, d in np.asarray(matches).reshape(-1, 3):
-            if d > max_dist or k1 >= self.counts[a] or k2 >= self.counts[b]:
-                continue
-            ra, rb = self.find(self.node(a, int(k1))), self.find(self.node(b, int(k2)))
-            if ra == rb or (self.frames[ra] & self.frames[rb]):
-                continue
-            self.parent[rb] = ra
-            self.frames[ra] |= self.frames[rb]
-
-    def tracks(self, min_len=2):
-        """Sorted list of tracks, each a sorted list of (frame, keypoint)."""
-        groups = {}
-        for f, c in enumerate(self.counts):
-            for k in range(c):
-                groups.setdefault(self.find(self.node(f, k)), []).append((f, k))
-        return sorted(sorted(g) for g in groups.values() if len(g) >= min_len)
-
-
-def build_track_graph(counts_all, pair_list, matches_all, max_dist=64):
-    """counts_all [F]; pair_list [(a, b)]; matches_all [M][cap][3] (tensor or array)."""
+def tracks_host(counts_all, pair_list, matches_all, max_dist=64, min_len=2):
+    """The track graph of gathered lists through the C ABI's HOST form (pgx_tracks_*: sequential, small inputs; what a host
+    without device-resident lists calls) -> (tracks, dropped components, nodes in them).  The device form is
+    ShardedSequence(tracks=...) / Engine.tracks_dev."""
+    from . import api
     m = matches_all.cpu().numpy() if isinstance(matches_all, torch.Tensor) else np.asarray(matches_all)
     c = counts_all.cpu().numpy() if isinstance(counts_all, torch.Tensor) else np.asarray(counts_all)
-    g = TrackGraph(c)
-    for p, (a, b) in enumerate(pair_list):
-        g.add_pair(a, b, m[p][:int(c[a])], max_dist)
-    return g
-
-
-def build_tracks_native(counts_all, pair_list, matches_all, max_dist=64, min_len=2):
-    """The same graph through the C ABI (pgx_tracks_*: what a non-Python host calls) -> list of tracks, each a list of
-    (frame, keypoint), in TrackGraph.tracks() order."""
-    import ctypes as C
-    from . import _lib
-    L = _lib.lib()
-    m = matches_all.cpu().numpy() if isinstance(matches_all, torch.Tensor) else np.asarray(matches_all)
-    c = np.ascontiguousarray(counts_all.cpu().numpy() if isinstance(counts_all, torch.Tensor) else counts_all, dtype=np.int32)
-    h = C.c_void_p()
-    if L.pgx_tracks_create(C.c_void_p(c.ctypes.data), len(c), C.byref(h)) != 0:
-        raise RuntimeError("pgx_tracks_create failed")
-    try:
-        for p, (a, b) in enumerate(pair_list):
-            rows = np.ascontiguousarray(m[p][:int(c[a])], dtype=np.int32)
-            if L.pgx_tracks_add_pair(h, int(a), int(b), C.c_void_p(rows.ctypes.data), len(rows), int(max_dist)) != 0:
-                raise RuntimeError("pgx_tracks_add_pair failed")
-        nt, nn = C.c_int(0), C.c_int(0)
-        if L.pgx_tracks_finish(h, int(min_len), C.byref(nt), C.byref(nn)) != 0:
-            raise RuntimeError("pgx_tracks_finish failed")
-        off = np.zeros(nt.value + 1, dtype=np.int32)
-        nodes = np.zeros((max(nn.value, 1), 2), dtype=np.int32)
-        if L.pgx_tracks_get(h, C.c_void_p(off.ctypes.data), C.c_void_p(nodes.ctypes.data)) != 0:
-            raise RuntimeError("pgx_tracks_get failed")
-        return [[(int(f), int(k)) for f, k in nodes[off[t]:off[t + 1]]] for t in range(nt.value)]
-    finally:
-        L.pgx_tracks_destroy(h)
+    return api.tracks_host(c, pair_list, [m[p] for p in range(len(pair_list))], max_dist, min_len)
 
 
 # ---- the four phases on this rank's GPU ------------------------------------------------------------
@@ -177,7 +106,7 @@ class ShardedSequence:
     the gathered buffers through slot_of(); the pair list handed to the matcher is pre-mapped."""
 
     def __init__(self, engine, W, H, n_frames, pair_list, nkp, words, device, stream=None, group=None, comm="torch",
-                 overlap_exchange=False):
+                 overlap_exchange=False, tracks=None):
         """comm = "torch": the two exchanges are torch.distributed all_gather_into_tensor calls (RCCL under the "nccl"
         backend, gloo in the CPU tests); comm = "pgx": the whole step is ONE C-ABI call, pgx_sequence_step_dev, on the
         context's own RCCL communicator (engine.comm_init must have run; what a non-Python host would use).
@@ -190,7 +119,14 @@ class ShardedSequence:
         estimated 0.4 ms of a 8.8 ms step (792 MB of lists at ~310 GB/s bus bandwidth = 2.2 ms against 1.75 ms of
         detect), nothing at <= 4 GPUs.  A second communicator would remove it, but two RCCL communicators with
         collectives in flight at once cannot be rehearsed on the one-GPU development box, and a hang costs the whole
-        run."""
+        run.
+        tracks = None | dict(max_dist=..., min_len=2, frames=None): build the track graph (pgx_tracks_dev) of every step's gathered
+        lists on this rank's GPU, on the job's stream, as soon as the lists are complete (right behind the matcher at G == 1,
+        behind the list gather otherwise -- with overlap_exchange that is one step later, or in finish()).  `frames` = the
+        global frame numbers this rank's graph covers, numbered 0.. in that order (default: all frames, i.e. every rank
+        builds the whole graph; a caller whose job is several independent sequences gives each rank its own sequences'
+        frames: image pairs touching other frames are skipped).  Results: track_of / trk_offsets / trk_nodes / trk_summary
+        (device), tracks() / track_summary() (host)."""
         assert comm in ("torch", "pgx")
         self.comm = comm
         self.overlap = bool(overlap_exchange) and comm == "torch"
@@ -224,6 +160,34 @@ class ShardedSequence:
         self.pairlist_l = torch.tensor(mapped if mapped else [[0, 0]], **i32)
         if self.on_gpu:
             engine.set_stream(self.stream.cuda_stream)
+        self.trk = None
+        if tracks is not None:
+            self.trk = {"max_dist": int(tracks.get("max_dist", 64)), "min_len": int(tracks.get("min_len", 2))}
+            frames = list(tracks["frames"]) if tracks.get("frames") is not None else list(range(n_frames))
+            ids = np.full(G * self.fs, -1, dtype=np.int32)
+            for i, f in enumerate(frames):
+                ids[slot_of(f, G, self.fs)] = i
+            self.trk_frames = frames
+            nfg = max(1, len(frames))
+            self.trk_frame_ids = torch.from_numpy(ids).to(device)
+            # the pair list of ALL image pairs in the row order of the gathered list buffer (padding rows name no frame)
+            rows = np.full((G * self.ps, 2), -1, dtype=np.int32)
+            for p, (a, b) in enumerate(self.pair_list):
+                rows[slot_of(p, G, self.ps)] = (slot_of(a, G, self.fs), slot_of(b, G, self.fs))
+            self.trk_pairlist = torch.from_numpy(rows).to(device)
+            self.track_of = torch.zeros((nfg, nkp), **i32)
+            self.trk_offsets = torch.zeros(nfg * nkp + 1, **i32)
+            self.trk_nodes = torch.zeros((nfg * nkp, 2), **i32)
+            self.trk_summary = torch.zeros(8, **i32)
+            # the counts a step's lists were made with, kept per output buffer: with the overlapped exchange the next step's
+            # detect has overwritten counts_all by the time the lists are complete
+            self.trk_counts = [torch.zeros(G * self.fs, **i32) for _ in self.out_bufs]
+
+    def _build_tracks(self, buf):
+        """Enqueue the track graph over the complete lists in out_bufs[buf] (on the job's stream)."""
+        self.e.tracks_dev(self.out_bufs[buf], self.trk_counts[buf], self.trk_pairlist, self.world * self.ps, self.world * self.fs,
+                          self.nkp, max(1, len(self.trk_frames)), self.trk["max_dist"], self.trk["min_len"], self.track_of,
+                          self.trk_offsets, self.trk_nodes, self.trk_summary, d_frame_ids=self.trk_frame_ids)
 
     def step(self, d_frames_local, after=None):
         """d_frames_local: uint16 [len(my_frames)][H][W][4] resident on this rank's GPU.
@@ -244,6 +208,9 @@ class ShardedSequence:
                     self.e.gate_match(other, gate_match)
             self.e.sequence_step_dev(d_frames_local, nf, self.fs, self.W, self.H, self.kp_l, self.desc_all, self.counts_all,
                                      self.nraw_l, self.nkp, self.pairlist_l, npr, self.ps, self.out_all)
+            if self.trk is not None:
+                self.trk_counts[0].copy_(self.counts_all)
+                self._build_tracks(0)
             return
         self.front(d_frames_local, after)
         self.back(after)
@@ -301,16 +268,24 @@ class ShardedSequence:
                 self.e.match_batch_dev(self.desc_all, self.counts_all, self.nkp, self.words, self.pairlist_l, npr,
                                        out_l, max_count=self.nkp)
             self.out_all, self.out_l = out_all, out_l
+            if self.trk is not None:
+                self.trk_counts[self._cur].copy_(self.counts_all)
             if self.world > 1:
                 if self.overlap:
                     # the gather issued one step ago filled the OTHER buffer; it has had this whole step to complete, and
                     # the next step's matcher writes into that buffer, so the stream waits for it here
                     if self._pending is not None:
                         self._pending.wait()
+                        if self.trk is not None:
+                            self._build_tracks(self._cur ^ 1)   # the previous step's lists are complete now
                     self._pending = dist.all_gather_into_tensor(out_all, out_l, group=self.group, async_op=True)
                     self._cur ^= 1
                 else:
                     dist.all_gather_into_tensor(out_all, out_l, group=self.group)
+                    if self.trk is not None:
+                        self._build_tracks(self._cur)
+            elif self.trk is not None:
+                self._build_tracks(self._cur)
 
     def finish(self):
         """Await the match-list exchange of the last step (overlap_exchange); a no-op otherwise."""
@@ -318,6 +293,8 @@ class ShardedSequence:
         if self._pending is not None:
             with (torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()):
                 self._pending.wait()
+                if self.trk is not None:
+                    self._build_tracks(self._cur ^ 1)   # the last step's lists
             self._pending = None
 
     # -- views for consumers (host side) ---------------------------------------------------------
@@ -331,3 +308,17 @@ class ShardedSequence:
 
     def matches(self, pair_index):
         return self.out_all[slot_of(pair_index, self.world, self.ps)]
+
+    def track_summary(self):
+        """pgx_tracks_dev's d_summary as a dict (synchronises)."""
+        v = self.trk_summary.cpu().tolist()
+        return {"n_tracks": v[0], "n_nodes": v[1], "dropped": v[2], "dropped_nodes": v[3], "edges": v[4], "longest": v[5],
+                "largest_dropped": v[6]}
+
+    def tracks(self):
+        """The most recent graph as a list of tracks, each a list of (frame, keypoint) in pgx_tracks_get's order; frames are
+        numbered as in the `frames` list given to the constructor (synchronises)."""
+        nt, nn = (int(x) for x in self.trk_summary[:2].cpu().tolist())
+        off = self.trk_offsets[:nt + 1].cpu().numpy()
+        nodes = self.trk_nodes[:nn].cpu().numpy()
+        return [[(int(f), int(k)) for f, k in nodes[off[t]:off[t + 1]]] for t in range(nt)]

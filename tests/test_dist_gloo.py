@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from oracle import cref
+from oracle import cref, tracks_np
 from photogrammetry_amd import dist as pdist
 from photogrammetry_amd import synth
 
@@ -90,8 +90,8 @@ def _worker(rank, world, port, q):
             out_l[k] = torch.from_numpy(_match(da[a], ca[a], da[b], ca[b]))
         # phase 4: one all-gather of the match lists
         out_all = pdist.exchange_matches(out_l, len(pl))
-        g = pdist.build_track_graph(cnt_all, pl, out_all, max_dist=40)
-        q.put((rank, desc_all.numpy(), cnt_all.numpy(), out_all.numpy(), g.tracks()))
+        tracks, _, _ = pdist.tracks_host(cnt_all, pl, out_all, max_dist=40)   # the C ABI's host form (no GPU work)
+        q.put((rank, desc_all.numpy(), cnt_all.numpy(), out_all.numpy(), tracks))
     finally:
         dist.destroy_process_group()
 
@@ -110,7 +110,7 @@ def test_pair_sharded_run_equals_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     desc, counts, pl, matches = _single_process()
-    ref_tracks = pdist.build_track_graph(counts, pl, matches, max_dist=40).tracks()
+    ref_tracks = tracks_np.tracks(counts, pl, matches, 40)[0]
     assert len(ref_tracks) > 5
     for rank, d, c, m, tracks in results:
         assert (d == desc).all() and (c == counts).all(), rank
@@ -127,30 +127,62 @@ def test_sharding_helpers():
     assert (pdist.all_gather_slots(t, 3) == t[:3]).all()
 
 
-def test_native_track_graph_equals_python():
-    """pgx_tracks_* (C ABI) against dist.TrackGraph on the 5-frame sequence and on random lists with conflicts."""
+def _random_lists(seed, F=7, kmax=9, dmax=60):
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(0, kmax, F).astype(np.int32)
+    pl = [(a, b) for a in range(F) for b in range(F) if a != b]
+    m = np.zeros((len(pl), kmax - 1, 3), dtype=np.int32)
+    m[..., 0] = rng.integers(0, kmax, m.shape[:2])
+    m[..., 1] = rng.integers(0, kmax, m.shape[:2])
+    m[..., 2] = rng.integers(0, dmax, m.shape[:2])
+    return counts, pl, m
+
+
+def test_host_track_graph_equals_oracle():
+    """pgx_tracks_* (the C ABI's host form) against the sequential oracle (oracle/tracks_np.py; parity unpinned by
+    construction: the reference has no track graph) on the 5-frame sequence and on random lists with conflicts."""
     desc, counts, pl, matches = _single_process()
     for md in (25, 40, 300):
-        assert pdist.build_tracks_native(counts, pl, matches, max_dist=md) == \
-               [list(t) for t in pdist.build_track_graph(counts, pl, matches, max_dist=md).tracks()]
-    rng = np.random.default_rng(5)
-    counts = rng.integers(0, 9, 7).astype(np.int32)
-    pl = [(a, b) for a in range(7) for b in range(7) if a != b]
-    m = np.zeros((len(pl), 8, 3), dtype=np.int32)
-    m[..., 0] = rng.integers(0, 9, m.shape[:2])
-    m[..., 1] = rng.integers(0, 9, m.shape[:2])
-    m[..., 2] = rng.integers(0, 60, m.shape[:2])
-    for min_len in (1, 2, 3):
-        got = pdist.build_tracks_native(counts, pl, m, max_dist=30, min_len=min_len)
-        assert got == [list(t) for t in pdist.build_track_graph(counts, pl, m, max_dist=30).tracks(min_len=min_len)]
+        exp, _, summ = tracks_np.tracks(counts, pl, matches, md)
+        got, dropped, dropped_nodes = pdist.tracks_host(counts, pl, matches, max_dist=md)
+        assert got == exp and (dropped, dropped_nodes) == (summ["dropped"], summ["dropped_nodes"])
+    for seed in range(6):
+        counts, pl, m = _random_lists(seed)
+        for min_len in (1, 2, 3):
+            for md in (5, 30):
+                exp, _, summ = tracks_np.tracks(counts, pl, m, md, min_len)
+                got, dropped, dropped_nodes = pdist.tracks_host(counts, pl, m, max_dist=md, min_len=min_len)
+                assert got == exp and (dropped, dropped_nodes) == (summ["dropped"], summ["dropped_nodes"])
 
 
-def test_track_graph_rejects_same_frame_merges():
-    g = pdist.TrackGraph([2, 2, 2])
-    g.add_pair(0, 1, [[0, 0, 5], [1, 1, 99]], max_dist=10)       # second edge fails the distance gate
-    g.add_pair(1, 2, [[0, 1, 3]], max_dist=10)
-    g.add_pair(0, 2, [[1, 1, 2]], max_dist=10)                   # would put (0,0) and (0,1) in one track
-    assert g.tracks() == [[(0, 0), (1, 0), (2, 1)]]
+def test_oracle_track_graph_two_formulations_agree():
+    """The sequential union-find and scipy's connected_components on the same gated edge set."""
+    for seed in range(8):
+        counts, pl, m = _random_lists(100 + seed, F=6 + seed % 3)
+        for md in (5, 20, 59):
+            a = tracks_np.tracks(counts, pl, m, md, 2)
+            b = tracks_np.tracks_csgraph(counts, pl, m, md, 2)
+            assert a[0] == b[0] and (a[1] == b[1]).all() and a[2] == b[2]
+    desc, counts, pl, matches = _single_process()
+    a, b = tracks_np.tracks(counts, pl, matches, 40), tracks_np.tracks_csgraph(counts, pl, matches, 40)
+    assert a[0] == b[0] and (a[1] == b[1]).all() and a[2] == b[2] and a[2]["n_tracks"] > 5
+
+
+def test_track_graph_drops_components_with_two_keypoints_of_one_frame():
+    counts = [2, 2, 2]
+    pl = [(0, 1), (1, 2), (0, 2)]
+    lists = [[[0, 0, 5], [1, 1, 99]],          # second edge fails the distance gate
+             [[0, 1, 3], [1, 0, 2**31 - 1]],   # the int.MaxValue tail never links, whatever the gate
+             [[1, 1, 2], [0, 0, 50]]]          # (0,1)-(2,1) puts (0,0) and (0,1) into one component
+    exp, track_of, summ = tracks_np.tracks(counts, pl, lists, 10)
+    assert exp == [] and summ["dropped"] == 1 and summ["dropped_nodes"] == 4 and (track_of[[0, 0, 1, 2], [0, 1, 0, 1]] == -2).all()
+    assert pdist.tracks_host(counts, pl, np.array(lists), max_dist=10) == ([], 1, 4)
+    lists[2] = [[1, 1, 20], [0, 0, 50]]        # without that edge: one consistent track
+    exp, track_of, summ = tracks_np.tracks(counts, pl, lists, 10)
+    assert exp == [[(0, 0), (1, 0), (2, 1)]] and summ["dropped"] == 0 and track_of[0, 1] == -1
+    assert pdist.tracks_host(counts, pl, np.array(lists), max_dist=10) == (exp, 0, 0)
+    # the order the pairs arrive in changes nothing
+    assert pdist.tracks_host(counts, pl[::-1], np.array(lists[::-1]), max_dist=10) == (exp, 0, 0)
 
 
 # ---- ShardedSequence (the class bench.py runs on the GPUs) on CPU tensors with a stand-in engine ----------
@@ -174,6 +206,27 @@ class _OracleEngine:
             a, b = int(pairlist[m, 0]), int(pairlist[m, 1])
             out[m] = torch.from_numpy(_match(d[a], int(c[a]), d[b], int(c[b])))
 
+    def tracks_dev(self, matches, counts, pairlist, M, F, stride, n_frames, max_dist, min_len, track_of, offsets, nodes, summary,
+                   d_frame_ids=None):
+        """pgx_tracks_dev's contract on CPU tensors, computed by the oracle (slots -> frame numbers, -1 slots skipped)."""
+        ids = d_frame_ids.numpy() if d_frame_ids is not None else np.arange(F)
+        c, pl, m = counts.numpy(), pairlist.numpy(), matches.numpy()
+        cnt = np.zeros(n_frames, dtype=np.int64)
+        for s_ in range(F):
+            if ids[s_] >= 0:
+                cnt[ids[s_]] = c[s_]
+        rows = [(int(ids[a]), int(ids[b]), m[r]) for r, (a, b) in enumerate(pl[:M]) if a >= 0 and b >= 0 and ids[a] >= 0 and ids[b] >= 0]
+        tr, tof, summ = tracks_np.tracks(cnt, [(a, b) for a, b, _ in rows], [x for _, _, x in rows], max_dist, min_len)
+        track_of.fill_(-1)
+        track_of[:, :tof.shape[1]] = torch.from_numpy(tof)
+        flat = [n for t in tr for n in t]
+        off = np.concatenate([[0], np.cumsum([len(t) for t in tr])]).astype(np.int32)
+        offsets[:len(off)] = torch.from_numpy(off)
+        if flat:
+            nodes[:len(flat)] = torch.tensor(flat, dtype=torch.int32)
+        summary[:] = torch.tensor([summ["n_tracks"], summ["n_nodes"], summ["dropped"], summ["dropped_nodes"], summ["edges"],
+                                   summ["longest"], summ["largest_dropped"], 0], dtype=torch.int32)
+
 
 def _seq_worker(rank, world, port, q, overlap=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -183,7 +236,8 @@ def _seq_worker(rank, world, port, q, overlap=False):
         pairs = cref.gaussian_pairs(0, 20, 256)
         fr = _frames()
         pl = pdist.all_pairs(N_FRAMES)
-        job = pdist.ShardedSequence(_OracleEngine(pairs), W, H, N_FRAMES, pl, CAP, 8, "cpu", overlap_exchange=overlap)
+        job = pdist.ShardedSequence(_OracleEngine(pairs), W, H, N_FRAMES, pl, CAP, 8, "cpu", overlap_exchange=overlap,
+                                    tracks={"max_dist": 40})
         mine = torch.from_numpy(np.stack([fr[f] for f in job.my_frames]))
         job.step(mine)
         job.step(mine)   # a second step over the same buffers must give the same answer
@@ -192,7 +246,7 @@ def _seq_worker(rank, world, port, q, overlap=False):
         job.finish()
         desc = np.stack([job.descriptors(f).numpy() for f in range(N_FRAMES)])
         out = np.stack([job.matches(p).numpy() for p in range(len(pl))])
-        q.put((rank, desc, job.counts(), out))
+        q.put((rank, desc, job.counts(), out, job.tracks(), job.track_summary()))
     finally:
         dist.destroy_process_group()
 
@@ -213,10 +267,13 @@ def test_sharded_sequence_equals_single_process(world, overlap):
         p.join(timeout=60)
         assert p.exitcode == 0
     desc, counts, pl, matches = _single_process()
-    for rank, d, c, m in results:
+    ref_tracks, _, ref_summ = tracks_np.tracks(counts, pl, matches, 40)
+    for rank, d, c, m, tracks, summ in results:
         assert (c == counts).all(), rank
         assert (d == desc).all(), rank
         assert (m == matches).all(), rank
+        # the track graph of the gathered lists (slot-addressed rank-major buffers, padding rows) = the single-process graph
+        assert tracks == ref_tracks and summ["n_tracks"] == ref_summ["n_tracks"] > 5, rank
 
 
 def _interleaved_worker(rank, world, port, q):

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import cref
+from oracle import cref, tracks_np
 from photogrammetry_amd import dist as pdist
 from photogrammetry_amd import synth
 import photogrammetry_amd as pg
@@ -59,7 +59,7 @@ def test_sharded_sequence_world1_config3_shape(engine):
         d_frames.view(torch.int64)[i] = torch.roll(d_base.view(torch.int64), shifts=(i % H, (3 * i) % W), dims=(0, 1))
     pl = pdist.all_pairs(F)
     stream = torch.cuda.Stream(device=DEV)
-    job = pdist.ShardedSequence(engine, W, H, F, pl, NKP, 8, DEV, stream=stream)
+    job = pdist.ShardedSequence(engine, W, H, F, pl, NKP, 8, DEV, stream=stream, tracks={"max_dist": 64, "min_len": 2})
     torch.cuda.synchronize()
     job.step(d_frames)
     job.step(d_frames)          # buffers are reused step after step
@@ -78,6 +78,14 @@ def test_sharded_sequence_world1_config3_shape(engine):
     for m, (a, b) in enumerate(pl):
         got = job.matches(m).cpu().numpy()[:counts[a]]
         assert _same(got, cref.match_sorted(desc[a], desc[b])), (a, b)
+    # the track graph the step built on the device from these 28 lists (pgx_tracks_dev; parity unpinned by
+    # construction -- the reference has no track graph) against the sequential oracle: same tracks, order, per-node ids
+    lists = np.stack([job.matches(m).cpu().numpy() for m in range(len(pl))])
+    exp, exp_tof, exp_s = tracks_np.tracks(counts, pl, lists, 64, 2)
+    assert job.tracks() == exp and exp_s["n_tracks"] > 1000
+    assert {k: v for k, v in job.track_summary().items()} == exp_s
+    tof = job.track_of.cpu().numpy()
+    assert (tof[:, :exp_tof.shape[1]] == exp_tof).all()
     engine.set_stream(0)
     engine.set_dewarp_map(None)
     engine.set_capacity(1 << 17, 1 << 20)

@@ -105,8 +105,7 @@ def main():
             ok &= bool((got[:, 0] == exp["k1"]).all() and (got[:, 1] == exp["k2"]).all() and (got[:, 2] == exp["dist"]).all())
         res["oracle_spot_check"] = {"pairs_checked": int(args.check), "bit_exact": ok}
         nf0 = sum(1 for a, b in pl if a == 0)   # the pairs of frame 0 come first in both orderings
-        g = pdist.build_track_graph(counts, pl[:nf0], out[:nf0], max_dist=40)
-        res["tracks_from_frame0_pairs"] = len(g.tracks())
+        res["tracks_from_frame0_pairs"] = len(pdist.tracks_host(counts, pl[:nf0], out[:nf0], max_dist=40)[0])
     print(json.dumps(res))
     eng.close()
 
