@@ -27,6 +27,11 @@ Extra objects on the JSON line:
   mfma          the metric's kernel (k_ham_fp4): achieved multiply-add op/s against the dense FP4 MFMA peak (10 PF)
   rooflines / kernels   every kernel group; traffic = HBM bytes from separate rocprofv3 --pmc passes (profiles/)
   match_only    pairs/s of the match stage alone (SURVEY 8d's definition of the metric)
+  tracks        the track graph of every step's match lists (pgx_tracks_dev): built INSIDE the timed step, on the
+                device, behind the matcher (N = 1) / behind the list gather (N > 1); counts, kernel time, and the check of
+                the timed job's graph against the sequential oracle
+  sustained     the same steps again for >= 3 s right after the headline region (outside `value`): a rate the driver's
+                clock and gpu_busy samples can corroborate
   configs       (N = 1) the other BASELINE configurations on this GPU: configs[1] x 64 independent pairs,
                 configs[3]'s one-GPU window variant (1024 x 3840x2160, 0 < j - i <= 16, 8192 keypoints)
   host_api      (N = 1) pgx_detect / pgx_match from HOST buffers (what a P/Invoke caller sees), PCIe included
@@ -56,6 +61,9 @@ MFMA_FP4 = True
 I8_MFMA_PEAK_OPS = 10.0e15   # name kept from round 1: operations of the 256-bit +-1 contraction per second (dense FP4 peak)
 HBM_PEAK = 8.0e12
 TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
+TRACK_MAX_DIST = 64   # the gate of the track graph: the reference's matchers took one (match_keypoints.py:23 default 75 on its own
+                      # descriptors; `new KeypointMatching(100)`, Program.cs:165); forced assignments of the greedy matcher on
+                      # 256-bit BRIEF sit near 100-128, true correspondences of the translated frames near 0
 
 
 def log(*a):
@@ -96,6 +104,10 @@ def parse_args(argv=None):
                     help="N > 1: after the timed region, run the same job once more through the C ABI's own RCCL communicator "
                          "(pgx_comm_init + pgx_sequence_step_dev) and compare.  Off by default: it loads a second RCCL instance next to "
                          "torch's, has never run at N > 1 (the development box has one GPU), and a crash or hang there would lose the headline line")
+    ap.add_argument("--no-tracks", action="store_true", help="do not build the track graph inside the step")
+    ap.add_argument("--track-max-dist", type=int, default=TRACK_MAX_DIST)
+    ap.add_argument("--sustain-s", type=float, default=3.2,
+                    help="after the headline region: run the same steps for about this long and report `sustained` (0 = skip)")
     ap.add_argument("--master-port", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -345,11 +357,48 @@ def verify_job(job, pair_list, host_frame0, dmap, pairs_tbl, FS):
     return res
 
 
+def verify_tracks(job, pair_list, track_frames, max_dist, summary):
+    """The track graph the timed job built on the device (this rank's: `track_frames`) against the oracle's vectorised
+    sequential restatement on the job's own gathered lists: offsets, nodes and per-node track ids array for array.
+    Parity is unpinned by construction (the reference has no track graph): this checks the parallel build."""
+    import numpy as np
+    from oracle import tracks_np
+    counts = job.counts()
+    fset = {f: i for i, f in enumerate(track_frames)}
+    rows = [(p, fset[a], fset[b]) for p, (a, b) in enumerate(pair_list) if a in fset and b in fset]
+    out = job.out_all.cpu().numpy()
+    m = np.stack([out[job_slot(job, p)] for p, _, _ in rows]) if rows else np.zeros((0, job.nkp, 3), np.int32)
+    e_off, e_nodes, e_tof, e_s = tracks_np.tracks_arrays(counts[track_frames], [(a, b) for _, a, b in rows], m, job.nkp, max_dist, 2)
+    nt, nn = summary["n_tracks"], summary["n_nodes"]
+    off = job.trk_offsets[:nt + 1].cpu().numpy()
+    nodes = job.trk_nodes[:nn].cpu().numpy()
+    tof = job.track_of.cpu().numpy()
+    ok = bool(summary == e_s and off.shape == e_off.shape and (off == e_off).all() and nodes.shape == e_nodes.shape
+              and (nodes == e_nodes).all() and (tof == e_tof).all())
+    lens = np.diff(e_off)
+    return {"n_tracks": int(nt), "n_nodes": int(nn), "mean_len": float(nn / nt) if nt else 0.0, "longest": int(summary["longest"]),
+            "dropped": int(summary["dropped"]), "dropped_nodes": int(summary["dropped_nodes"]),
+            "largest_dropped": int(summary["largest_dropped"]), "edges": int(summary["edges"]),
+            "match_entries": int(len(rows) * job.nkp), "frames": len(track_frames), "image_pairs": len(rows),
+            "max_dist": int(max_dist), "min_len": 2,
+            "len_histogram": {str(k): int(v) for k, v in zip(*np.unique(np.minimum(lens, 64), return_counts=True))} if len(lens) else {},
+            "semantics": "nodes (frame, keypoint); edges = match entries with dist <= max_dist; tracks = connected components with >= 2 "
+                         "nodes; a component with two keypoints of one frame is dropped whole (include/pgx.h)",
+            "verified": {"ok": ok, "what": "offsets, nodes and per-node track ids of the timed job's graph == oracle/tracks_np.tracks_arrays "
+                                           "(numpy + scipy connected components) on the job's own lists; parity unpinned by construction "
+                                           "(no track graph in the reference)"}}
+
+
+def job_slot(job, p):
+    from photogrammetry_amd import dist as pdist
+    return pdist.slot_of(p, job.world, job.ps)
+
+
 # ---------------------------------------------------------------------------------------------------
 # one rank
 # ---------------------------------------------------------------------------------------------------
 
-KERNEL_GROUPS = ("dewarp_gray", "fast", "nms", "brief", "match_init", "ham_argmin", "match_select", "tail_fill", "tail_rows", "match_finish")
+KERNEL_GROUPS = ("dewarp_gray", "fast", "nms", "brief", "match_init", "ham_argmin", "match_select", "tail_fill", "tail_rows", "match_finish", "tracks")
 
 
 def kernel_table(engs, steps):
@@ -403,6 +452,11 @@ def worker(args):
     pair_list = [(s * FS + i, s * FS + j) for s in range(nseq) for i in range(FS) for j in range(i + 1, FS)]
     pairs = pg.make_brief_pairs(0, 50, P)
     dmap = None if args.no_dewarp else pg.build_dewarp_map(W, H, [3e-4, 1e-7, 0, 0, 0])
+    # The track graph of every step, built on the device inside the step.  Weak scaling: the job is `world`
+    # independent sequences and every gathered list is on every rank, so rank r builds the graph of sequence r (no rank
+    # idles, no extra exchange); strong scaling: one sequence, every rank builds the same whole graph (a replica each).
+    track_frames = list(range(rank * FS, (rank + 1) * FS)) if args.scaling == "weak" else list(range(n_frames))
+    track_cfg = None if args.no_tracks else {"max_dist": args.track_max_dist, "min_len": 2, "frames": track_frames}
     NI = max(1, args.in_flight)
     stage_of = {"none": None, "detect": 0, "wide": 1, "rows": 2, "done": 3}   # PGX_STAGE_*
     GATES = tuple(stage_of[x] for x in args.gate.split(","))
@@ -418,7 +472,7 @@ def worker(args):
         e.set_dewarp_map(dmap)
         engs.append(e)
         jobs.append(pdist.ShardedSequence(e, W, H, n_frames, pair_list, NKP, WORDS, dev, stream=torch.cuda.Stream(device=dev),
-                                          overlap_exchange=not args.no_overlap_exchange))
+                                          overlap_exchange=not args.no_overlap_exchange, tracks=track_cfg))
     eng, job = engs[0], jobs[0]
     stream = job.stream
 
@@ -504,6 +558,41 @@ def worker(args):
     per_pair = float(max(1, args.steps * max(1, len(job.my_pairs))))
     tail_scans_per_pair, tail_props_per_pair = dbg[4] / per_pair, dbg[6] / per_pair
     kern_timed = kernel_table(engs, args.steps) if rank == 0 else {}
+    track_summary = job.track_summary() if track_cfg else None
+
+    # sustained leg: the same steps, same schedule, for about --sustain-s seconds (every rank the same count: it is derived
+    # from the max-over-ranks time of the headline region); outside `value`
+    sustained = None
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t[0].item())
+    if args.sustain_s > 0:
+        n_sus = max(NI, int(args.sustain_s / max(dt_max / args.steps, 1e-6)) + 1)
+        for e in engs:
+            e.profile_reset()
+            e.profile_filter("ham_argmin")
+            e.profile_enable(not args.no_profile)   # the same instrumentation as the headline region
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(n_sus)
+        for j in jobs:
+            j.finish()
+        barrier()
+        ts = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        for e in engs:
+            e.profile_enable(False)
+            e.profile_filter(None)
+            e.check_status()
+            e.debug_counters()
+        for j in jobs[1:]:
+            assert torch.equal(j.out_all, job.out_all) and torch.equal(j.counts_all, job.counts_all)
+        sustained = {"steps": n_sus, "seconds": float(ts[0].item()), "ms_per_step": float(ts[0].item()) / n_sus * 1e3,
+                     "value": pairs_per_step * n_sus / float(ts[0].item()),
+                     "what": "the headline job again, same schedule and instrumentation, right after the headline region; not part of `value`"}
+        log("[rank %d] sustained: %d steps in %.2f s = %.3f ms per step" % (rank, n_sus, sustained["seconds"], sustained["ms_per_step"]))
     # stand-alone kernel times: in the timed region three matcher stages of consecutive chunks share the chip, so their
     # event brackets overlap and stretch each other; a second, untimed pass runs the same steps with the stages in order
     kern_alone, k_alone = {}, max(3, min(20, args.steps))
@@ -521,11 +610,6 @@ def worker(args):
         if rank == 0:
             kern_alone = kernel_table(eng, k_alone)
     log('finish (k_match_gs) per image pair: queue entries %.1f, matrix-row scans %.1f, proposals %.1f' % (dbg[3] / per_pair, tail_scans_per_pair, tail_props_per_pair))
-
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t[0].item())
 
     # N > 1: the same job once more through the C ABI's own communicator (pgx_comm_init / pgx_sequence_step_dev: what a
     # non-Python host would call) -- results must equal the torch.distributed run; informative, never `value`
@@ -562,6 +646,13 @@ def worker(args):
         t_v = time.time()
         verified = verify_job(job, pair_list, host_base0, dmap, pairs, FS)
         log("verification of the timed job took %.1fs: %s" % (time.time() - t_v, "ok" if verified["ok"] else "MISMATCH"))
+        tracks_obj = None
+        if track_cfg:
+            t_v = time.time()
+            tracks_obj = verify_tracks(job, pair_list, track_frames, args.track_max_dist, track_summary)
+            log("track graph check took %.1fs: %s" % (time.time() - t_v, "ok" if tracks_obj["verified"]["ok"] else "MISMATCH"))
+            verified["tracks_ok"] = tracks_obj["verified"]["ok"]
+            verified["ok"] = bool(verified["ok"] and tracks_obj["verified"]["ok"])
         if not verified["ok"]:
             rc = 4
         F_l, M_l = len(job.my_frames), len(job.my_pairs)
@@ -665,6 +756,8 @@ def worker(args):
                        "rehearsal_on_one_gpu_with_gloo": rehearse},
             "roofline": rooflines.get(dominant),
             "verified": verified,
+            "tracks": tracks_obj,
+            "sustained": sustained,
             "mfma": mfma,
             "c_abi_comm": c_abi,
             "traffic_note": traffic_src,
@@ -686,6 +779,13 @@ def worker(args):
                            if detect_ms else None,
                            "note": "match stage wall = step minus the detect kernels (rank 0); SURVEY 8d's match-only definition"},
         }
+        if tracks_obj is not None:
+            tracks_obj["ms_per_step"] = kern["tracks"]["ms_per_step"] if "tracks" in kern else None
+            tracks_obj["in_timed_region"] = True
+            tracks_obj["built_by"] = ("rank r builds the graph of sequence r (all lists are on every rank after the gather)" if args.scaling == "weak"
+                                      else "every rank builds the whole graph of the one sequence (replicas)") if world > 1 else "the one GPU"
+            tracks_obj["ms_per_step_note"] = ("kernel time of pgx_tracks_dev's launches from the untimed stand-alone pass (HIP events); the "
+                                              "graph IS built inside every timed step, so ms_per_step / value include it")
         if world == 1 and not args.no_extra_configs:
             try:
                 result["configs"] = extra_configs(torch, pg, pdist, np, eng, dev, stream, pairs, dmap)

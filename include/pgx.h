@@ -298,9 +298,10 @@ int pgx_profile_serialize(pgx_ctx *ctx, int on);
  * n1*n2; evaluations_round0 = the first launch alone = sum of N1*N2).  Synchronises the stream. */
 int pgx_match_stats(pgx_ctx *ctx, int *rounds_wide, int64_t *evaluations, int64_t *evaluations_round0);
 
-/* Diagnostic counters of the match tail since the last call (pairs, sum R, sum C, rounds, row
- * re-scans, column re-scans, 0, 0); cleared on read.  Synchronises the stream. */
-int pgx_debug_counters(pgx_ctx *ctx, int32_t *out8);
+/* Diagnostic counters of the match tail since the last call, 64-bit (they count per image pair and step: a long run
+ * overflows 32 bits): [3] queue entries, [4] matrix-row scans, [6] proposals of the per-pair finish; the others are
+ * used by developer builds only.  Cleared on read.  Synchronises the stream. */
+int pgx_debug_counters(pgx_ctx *ctx, int64_t *out8);
 
 /* ---- host-side helpers (no GPU work) -------------------------------------------------- */
 /* Utils.NextGaussianPair (Utils.cs:14-38) on a seeded splitmix64 stream; out [P][4]. */

@@ -283,7 +283,7 @@ class Engine:
                                                 _dptr(d_out_all)))
 
     def debug_counters(self):
-        out = np.zeros(8, dtype=np.int32)
+        out = np.zeros(8, dtype=np.int64)
         self._chk(self._L.pgx_debug_counters(self._h, _ptr(out)))
         return out.tolist()
 

@@ -467,7 +467,7 @@ __host__ __device__ inline size_t tail_lds_words(int W)
 
 template <int WORDS>
 __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict__ dA, const uint32_t *__restrict__ dB,
-                                int words_rt, uint32_t *lds, int *dbg)
+                                int words_rt, uint32_t *lds, unsigned long long *dbg)
 {
     const int W = WORDS > 0 ? WORDS : words_rt;
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nth >> 6;
@@ -600,7 +600,7 @@ __device__ void tail_rounds_lds(PairWs p, int parity, const uint32_t *__restrict
 
     while (true) {
         const int nrd = (int)ctr[0], ncd = (int)ctr[1];
-        if (tid == 0) { atomicAdd(&dbg[3], 1); atomicAdd(&dbg[4], nrd); atomicAdd(&dbg[5], ncd); }
+        if (tid == 0) { atomicAdd(&dbg[3], 1ull); atomicAdd(&dbg[4], (unsigned long long)nrd); atomicAdd(&dbg[5], (unsigned long long)ncd); }
         scan_dirty(nrd, ncd);
         __syncthreads();
         if (tid == 0) { ctr[0] = 0; ctr[1] = 0; ctr[3] = 0; ctr[4] = 0; }
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(SEL_NT) void k_match_finish(uint32_t *ws, const uin
         if (n1 <= 0 || n2 <= 0) break; // uniform: cnt is only written behind barriers
         const int lim = PGX_TAIL_FILL_MAX; // the descriptors of the residual must fit LDS
         if (tail_in_lds && n1 <= lim && n2 <= lim) {
-            tail_rounds_lds<WORDS>(p, parity, dA, dB, words, lds, status + 24);
+            tail_rounds_lds<WORDS>(p, parity, dA, dB, words, lds, pgx_dbg(status));
             break;
         }
         ham_rows_vs_cols<WORDS>(dA, (parity ? p.rows1 : p.rows0), n1, dB, (parity ? p.cols1 : p.cols0), 0, n2, 0, words, p.rowkey, false, lds);

@@ -14,7 +14,7 @@
 //   k_trk_init     parent[x] = x, zeroes, empty per-frame hash tables, track_of = -1
 //   k_trk_union    one thread per match entry: lock-free union, the larger root hooks under the smaller (atomicCAS), so a
 //                  component's root ends up its smallest node id whatever the schedule
-//   k_trk_flatten  one thread per node: root, component size (atomicAdd), and the frame-conflict test: the node's root goes
+//   k_trk_flatten  one thread per node: root (into its own array), component size (atomicAdd), and the frame-conflict test: the node's root goes
 //                  into its FRAME's hash table (open addressing, atomicCAS); finding it there already = two keypoints of one
 //                  frame in one component
 //   k_trk_scan_*   exclusive scan over node ids of (kept roots, their sizes): track index and node offset in root order
@@ -38,7 +38,7 @@ struct TrkArgs {
     int M, F, stride, n_frames, max_dist, min_len;
     long long N;               // n_frames * stride
     int T;                     // hash table entries per frame (power of two >= 2 * stride)
-    int32_t *parent, *size, *flag, *cursor, *tidx, *noff, *tmp;
+    int32_t *parent, *root, *size, *flag, *cursor, *tidx, *noff, *tmp;
     uint32_t *table;           // [n_frames][T]
     unsigned long long *bsum;  // per scan block: (kept roots << 32) | their nodes
     int32_t *track_of, *offsets, *nodes, *summary;
@@ -132,7 +132,8 @@ __global__ __launch_bounds__(TRK_NT) void k_trk_flatten(TrkArgs a)
     if (k >= c) return;
     const int x = f * a.stride + k;
     const int r = trk_find(a.parent, x);
-    st(a.parent + x, r);
+    // into an array of its own: other threads' pointer jumping still stores (older) ancestors into parent[x] while this runs
+    a.root[x] = r;
     atomicAdd(a.size + r, 1);
     // the root into this frame's table; already there = a second keypoint of this frame in the component
     uint32_t *tab = a.table + (size_t)f * a.T;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(TRK_NT) void k_trk_place(TrkArgs a)
     c = c > a.stride ? a.stride : c;
     if (k >= c) return;
     const int x = f * a.stride + k;
-    const int r = a.parent[x];
+    const int r = a.root[x];
     if (a.flag[r]) { a.track_of[x] = -2; return; }
     const int sz = a.size[r];
     if (sz < a.min_len) return;   // track_of stays -1
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(TRK_NT) void k_trk_rank(TrkArgs a)
     c = c > a.stride ? a.stride : c;
     if (k >= c) return;
     const int x = f * a.stride + k;
-    const int r = a.parent[x];
+    const int r = a.root[x];
     const int sz = a.size[r];
     if (a.flag[r] || sz < a.min_len) return;
     const int o = a.noff[r];
@@ -293,7 +294,7 @@ size_t pgx_tracks_ws_bytes(int n_frames, int stride)
     int T = 64;
     while (T < 2 * stride) T <<= 1;
     const size_t nb = (N + SCAN_ITEMS - 1) / SCAN_ITEMS;
-    return 7 * N * 4 + (size_t)n_frames * T * 4 + nb * 8 + 1024;
+    return 8 * N * 4 + (size_t)n_frames * T * 4 + nb * 8 + 1024;
 }
 
 void pgx_launch_tracks(hipStream_t s, const pgx_pair *d_matches, const int32_t *d_counts, const int32_t *d_pairlist, int M, int F,
@@ -309,8 +310,9 @@ void pgx_launch_tracks(hipStream_t s, const pgx_pair *d_matches, const int32_t *
     const size_t N = (size_t)a.N;
     int32_t *w = static_cast<int32_t *>(ws);
     a.parent = w; a.size = w + N; a.flag = w + 2 * N; a.cursor = w + 3 * N; a.tidx = w + 4 * N; a.noff = w + 5 * N; a.tmp = w + 6 * N;
-    a.table = reinterpret_cast<uint32_t *>(w + 7 * N);
-    const size_t tab_end = (7 * N + (size_t)n_frames * a.T) * 4;
+    a.root = w + 7 * N;
+    a.table = reinterpret_cast<uint32_t *>(w + 8 * N);
+    const size_t tab_end = (8 * N + (size_t)n_frames * a.T) * 4;
     a.bsum = reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + ((tab_end + 7) & ~(size_t)7));
     a.track_of = d_track_of; a.offsets = d_offsets; a.nodes = d_nodes; a.summary = d_summary;
 

@@ -4,6 +4,7 @@
 // every entry point needs a working gfx950 device and fails with PGX_E_HIP without one.
 #include "pgx_internal.h"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <new>
@@ -14,11 +15,14 @@
 
 static thread_local std::string tl_err;
 static thread_local const pgx_ctx *tl_err_ctx = nullptr;
+static thread_local unsigned long long tl_err_id = 0;   // the context's id: a new context at a dead one's address is not it
+static std::atomic<unsigned long long> g_ctx_ids{0};
 
 void pgx_note_error(pgx_ctx *c, const std::string &msg)
 {
     tl_err = msg;
     tl_err_ctx = c;
+    tl_err_id = c ? c->id : 0;
     if (c) {
         std::lock_guard<std::mutex> g(c->err_mu);
         c->err = msg;
@@ -158,6 +162,10 @@ int prepare_match(pgx_ctx *c, int stride, int words, int M)
 int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, int stride, int words,
                   const int32_t *d_pairlist, int M, int max_n, pgx_pair *d_out)
 {
+    // pgx_gate_match is one shot on the NEXT matcher call, whatever becomes of that call: taken and cleared before any
+    // early return, so that a gate never stays armed for some later call (its event belongs to another context)
+    hipEvent_t gate = c->match_gate;
+    c->match_gate = nullptr;
     if (M <= 0) return PGX_OK;
     const int rcp = prepare_match(c, stride, words, M);
     if (rcp != PGX_OK) return rcp;
@@ -185,8 +193,6 @@ int enqueue_match(pgx_ctx *c, const uint32_t *d_desc, const int32_t *d_counts, i
     // stage of the matcher is bound by vector-instruction issue, so running the stages of consecutive chunks side by side
     // buys nothing (round 4: 6.43 ms side by side against 6.25 in order at 1024 pairs per chunk), while a large chunk gives
     // the per-pair finish several workgroups per CU to balance (2016 pairs in one chunk: 6.0 ms).
-    hipEvent_t gate = c->match_gate; // one shot (pgx_gate_match)
-    c->match_gate = nullptr;
     if (M <= CHUNK || c->prof_serial || CHUNK >= PGX_PIPELINE_BELOW) { // everything in order on the context's stream
         for (int m0 = 0; m0 < M; m0 += CHUNK) {
             plan.M = (M - m0 < CHUNK) ? M - m0 : CHUNK;
@@ -291,6 +297,7 @@ int pgx_ctx_create(int device, pgx_ctx **out)
     pgx_ctx *c = new (std::nothrow) pgx_ctx();
     if (!c) return PGX_E_HIP;
     c->device = device;
+    c->id = ++g_ctx_ids;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_stage[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_stage[1], hipEventDisableTiming) != hipSuccess ||
@@ -340,7 +347,7 @@ void pgx_ctx_destroy(pgx_ctx *c)
 const char *pgx_last_error(pgx_ctx *c)
 {
     if (!c) return "null context";
-    if (tl_err_ctx == c) return tl_err.c_str();   // this thread's own last failure on this context
+    if (tl_err_ctx == c && tl_err_id == c->id) return tl_err.c_str();   // this thread's own last failure on this context
     static thread_local std::string copy;         // another thread's: a private copy, valid until this thread asks again
     {
         std::lock_guard<std::mutex> g(c->err_mu);
@@ -353,6 +360,7 @@ int pgx_set_stream(pgx_ctx *c, void *hip_stream)
 {
     if (!c) return PGX_E_BADARG;
     Lock l(c);
+    c->cfg_epoch++;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
     return PGX_OK;
@@ -369,6 +377,7 @@ int pgx_set_dewarp_map(pgx_ctx *c, const int32_t *uv, int W, int H)
 {
     if (!c) return PGX_E_BADARG;
     Lock l(c);
+    c->cfg_epoch++;
     if (!uv) { c->map_set = false; c->mapW = c->mapH = 0; return PGX_OK; }
     if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return fail(c, PGX_E_BADARG, "map dimensions must fit ushort");
     const size_t bytes = (size_t)W * H * 8;
@@ -383,6 +392,7 @@ int pgx_set_dewarp_coeffs(pgx_ctx *c, int W, int H, const double *coeffs, int nc
 {
     if (!c || !coeffs) return c ? fail(c, PGX_E_BADARG, "null pointer") : PGX_E_BADARG;
     Lock l(c);
+    c->cfg_epoch++;
     if (ncoeffs != 5) return fail(c, PGX_E_BADARG, "You must pass exactly 5 distortion coefficients (ArgumentException)"); // DeWarp.cs:46-48
     if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return fail(c, PGX_E_BADARG, "map dimensions must fit ushort");
     const size_t bytes = (size_t)W * H * 8;
@@ -409,6 +419,7 @@ int pgx_set_brief_pairs(pgx_ctx *c, const int32_t *pairs, int P)
 {
     if (!c) return PGX_E_BADARG;
     Lock l(c);
+    c->cfg_epoch++;
     if (!pairs || P <= 0 || P > 4064) return fail(c, PGX_E_BADARG, "P must be in [1, 4064]");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, c->d_pairs.ensure((size_t)P * 16));
@@ -421,6 +432,7 @@ int pgx_set_detect_params(pgx_ctx *c, float threshold, int suppression_radius)
 {
     if (!c) return PGX_E_BADARG;
     Lock l(c);
+    c->cfg_epoch++;
     c->threshold = threshold; c->radius = suppression_radius; c->params_set = true;
     return PGX_OK;
 }
@@ -429,6 +441,7 @@ int pgx_set_match_chunk(pgx_ctx *c, int pairs)
 {
     if (!c) return PGX_E_BADARG;
     Lock l(c);
+    c->cfg_epoch++;
     if (pairs < 16 || pairs > 4096) return fail(c, PGX_E_BADARG, "image pairs per chunk must be in [16, 4096]");
     c->match_chunk = pairs;
     return PGX_OK;
@@ -462,6 +475,7 @@ int pgx_set_source_format(pgx_ctx *c, int format)
 {
     if (!c) return PGX_E_BADARG;
     Lock l(c);
+    c->cfg_epoch++;
     if (format != PGX_SRC_RGBA64 && format != PGX_SRC_RGBA8) return fail(c, PGX_E_BADARG, "unknown source format %d", format);
     c->src8 = format == PGX_SRC_RGBA8;
     return PGX_OK;
@@ -471,6 +485,7 @@ int pgx_set_capacity(pgx_ctx *c, int max_raw, int max_kp)
 {
     if (!c) return PGX_E_BADARG;
     Lock l(c);
+    c->cfg_epoch++;
     if (max_raw <= 0 || max_kp <= 0 || max_kp > (1 << PGX_IDX_BITS)) return fail(c, PGX_E_BADARG, "bad capacity");
     c->raw_cap = max_raw; c->kp_cap = max_kp;
     return PGX_OK;
@@ -867,13 +882,13 @@ int pgx_profile_reset(pgx_ctx *c)
     return PGX_OK;
 }
 
-int pgx_debug_counters(pgx_ctx *c, int32_t *out8)
+int pgx_debug_counters(pgx_ctx *c, int64_t *out8)
 {
     if (!c || !out8) return PGX_E_BADARG;
     Lock l(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out8, c->d_status + 24, 32, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemset(c->d_status + 24, 0, 32));
+    HIPCHK(c, hipMemcpy(out8, c->d_status + PGX_DBG_OFF, 64, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemset(c->d_status + PGX_DBG_OFF, 0, 64));
     return PGX_OK;
 }
 

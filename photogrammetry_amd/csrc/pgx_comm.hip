@@ -10,8 +10,9 @@
 //
 // Failure on ONE rank: a collective is a rendezvous, so a rank that returned early would leave its peers waiting in the
 // all-gather for ever.  pgx_sequence_step_dev therefore does every rank-local check and every workspace allocation BEFORE
-// the first collective and -- on the first call with a given set of arguments -- ends that part with a one-int status
-// exchange that the failing rank joins too: every rank returns an error, nobody waits.  A HIP or RCCL error in the middle
+// the first collective and -- on the first call, and again whenever the rank-symmetric arguments or the configuration
+// epoch change -- ends that part with a one-int status exchange that the failing rank joins too: every rank returns an
+// error, nobody waits.  The decision to exchange never depends on rank-local state (see the function).  A HIP or RCCL error in the middle
 // of a step (after that point) makes the rank abort its communicator (ncclCommAbort, a required symbol); that is best
 // effort: on one node the peers' collective kernels may spin on shared flags without noticing, so the host must time
 // its ranks out.  N > 1 on RCCL has only ever run under the driver's multi-GPU bench (the development box has one GPU);
@@ -119,6 +120,7 @@ int pgx_comm_init(pgx_ctx *c, int rank, int world, const void *id)
     c->comm = comm;
     c->comm_rank = rank;
     c->comm_world = world;
+    c->comm_agreed.clear();
     return PGX_OK;
 }
 
@@ -133,6 +135,7 @@ int pgx_comm_destroy(pgx_ctx *c)
     c->comm = nullptr;
     c->comm_rank = 0;
     c->comm_world = 1;
+    c->comm_agreed.clear();
     return rc == ncclSuccessV ? PGX_OK : comm_fail(c, "ncclCommDestroy", rc);
 }
 
@@ -166,29 +169,36 @@ int pgx_sequence_step_dev(pgx_ctx *c, const uint16_t *d_frames_local, int n_loca
                           int capacity, const int32_t *d_pairlist_local, int n_local_pairs, int pair_slots,
                           pgx_pair *d_out_all)
 {
-    if (!c || !d_desc_all || !d_counts_all || !d_out_all || capacity <= 0 || frame_slots < 0 || pair_slots < 0 ||
-        n_local_frames < 0 || n_local_frames > frame_slots || n_local_pairs < 0 || n_local_pairs > pair_slots ||
-        (n_local_frames > 0 && (!d_frames_local || !d_kp_local || !d_nraw_local)) || (n_local_pairs > 0 && !d_pairlist_local))
-        return c ? (pgx_note_error(c, "bad argument"), PGX_E_BADARG) : PGX_E_BADARG;
+    if (!c) return PGX_E_BADARG;
     std::lock_guard<std::mutex> g(c->mu);
     (void)hipSetDevice(c->device);
     if (c->comm_world > 1 && !c->comm) { pgx_note_error(c, "pgx_comm_init not called"); return PGX_E_NOT_CONFIGURED; }
     const int words = c->words, r = c->comm_rank;
     // Every rank-local check and allocation first: nothing below this block fails for a local reason in normal operation.
-    // A rank that does fail here (not configured, a size mismatch, no memory) must not leave its peers waiting in the first
-    // all-gather, so the FIRST call with a given set of arguments ends this block with a status exchange -- one int per rank
-    // through the same all-gather, which the failing rank joins too -- and every rank returns an error if any rank failed.
-    // The failures in question are properties of the arguments and of what is already allocated (workspaces only grow), so
-    // later calls with the same arguments skip the exchange: it costs a host synchronisation.
+    // A rank that does fail here (a bad argument, not configured, a size mismatch, no memory) must not leave its peers waiting
+    // in the first all-gather, so this block ends with a status exchange -- one int per rank through the same all-gather,
+    // which the failing rank joins too -- and every rank returns an error if any rank failed.
+    // WHETHER the exchange runs must be the same decision on every rank, or the ranks issue different collectives.  It is
+    // therefore taken from nothing but (a) the arguments that the contract requires to be equal on all ranks -- slot counts,
+    // image size, capacity -- and (b) the context's configuration epoch, which every pgx_set_* call bumps (configuration
+    // calls are init-time and must be made on every rank alike): the exchange runs on the first call and whenever that key
+    // changes, NEVER because of this rank's own rc or its own share of the work (n_local_*: the last batch may be short on
+    // one rank only).  A rank that fails locally under an agreed key (e.g. a larger local share that no longer fits) cannot
+    // tell its peers through a collective they are not going to issue: it aborts its communicator like any mid-step failure.
     int rc = PGX_OK;
-    if (!c->pairs_set) { pgx_note_error(c, "pgx_set_brief_pairs not called"); rc = PGX_E_NOT_CONFIGURED; }
+    if (!d_desc_all || !d_counts_all || !d_out_all || capacity <= 0 || frame_slots < 0 || pair_slots < 0 ||
+        n_local_frames < 0 || n_local_frames > frame_slots || n_local_pairs < 0 || n_local_pairs > pair_slots ||
+        (n_local_frames > 0 && (!d_frames_local || !d_kp_local || !d_nraw_local)) || (n_local_pairs > 0 && !d_pairlist_local)) {
+        pgx_note_error(c, "bad argument");
+        rc = PGX_E_BADARG;
+    }
+    if (rc == PGX_OK && !c->pairs_set) { pgx_note_error(c, "pgx_set_brief_pairs not called"); rc = PGX_E_NOT_CONFIGURED; }
     if (rc == PGX_OK) rc = pgx_prepare_detect(c, n_local_frames, W, H, capacity);
     if (rc == PGX_OK) rc = pgx_prepare_match(c, capacity, words, n_local_pairs);
     if (c->comm_world > 1) {
         char key[160];
-        snprintf(key, sizeof key, "%d/%d/%dx%d/%d/%d/%d/%d/%d", n_local_frames, frame_slots, W, H, capacity, n_local_pairs, pair_slots,
-                 words, c->radius);
-        if (rc != PGX_OK || c->comm_agreed != key) {
+        snprintf(key, sizeof key, "%d/%dx%d/%d/%d/e%u", frame_slots, W, H, capacity, pair_slots, c->cfg_epoch);
+        if (c->comm_agreed != key) {
             const std::string own = rc != PGX_OK ? std::string(pgx_last_error(c)) : std::string();
             const int G = c->comm_world;
             std::vector<int> st((size_t)G, 0);
@@ -211,6 +221,14 @@ int pgx_sequence_step_dev(pgx_ctx *c, const uint16_t *d_frames_local, int n_loca
                     return PGX_E_RCCL;
                 }
             c->comm_agreed = key;
+        } else if (rc != PGX_OK) {
+            // a local failure under an agreed key: the peers are about to issue the step's all-gathers, not a status exchange
+            const std::string own(pgx_last_error(c));
+            (void)rccl()->CommAbort(reinterpret_cast<ncclComm_t>(c->comm));
+            c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+            c->comm_agreed.clear();
+            pgx_note_error(c, own + " (after the ranks had agreed on these arguments: communicator aborted)");
+            return rc;
         }
     } else if (rc != PGX_OK) return rc;
     // From here on a local failure is a HIP or RCCL error in the middle of the step.  The communicator is aborted so that

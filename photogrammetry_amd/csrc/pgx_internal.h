@@ -26,6 +26,8 @@
 #define PGX_KEY_NONE 0xFFFFFFFFu
 // d_status layout (ints): [0] sticky error bits, [4..4+2*PGX_MAX_WIDE_ROUNDS) u64 evaluation counters per wide round
 #define PGX_MAX_WIDE_ROUNDS 8
+// ... and [PGX_DBG_OFF .. +16) eight u64 diagnostic counters of the match tail (pgx_debug_counters)
+#define PGX_DBG_OFF 32
 // residual size (rows and columns) from which one workgroup finishes an image pair out of LDS
 #define PGX_TAIL_MAX 2048
 // ... and the limit when the tail workgroup has to fill its distance cache itself (descriptors staged in LDS)
@@ -124,7 +126,9 @@ struct pgx_ctx {
     // multi-GPU: the RCCL communicator of this context's process (pgx_comm.hip); world 1 = none
     void *comm = nullptr;
     int comm_rank = 0, comm_world = 1;
-    std::string comm_agreed;   // arguments of the last pgx_sequence_step_dev whose local part every rank confirmed
+    std::string comm_agreed;   // rank-symmetric arguments + cfg_epoch of the last pgx_sequence_step_dev whose local part every rank confirmed
+    unsigned cfg_epoch = 0;    // bumped by every pgx_set_* call (the status exchange of pgx_sequence_step_dev runs again after one)
+    unsigned long long id = 0; // unique per created context (pgx_last_error tells a new context from a dead one at the same address)
     DevBuf ws_agree;
 
     // profiling
@@ -144,6 +148,7 @@ struct pgx_ctx {
 // inside a group of 8 frames and one frame's working set lives in ONE XCD's 4 MiB L2.  Speed only: any
 // mapping is correct.  Launch with a 1-D grid of nblk * F blocks.
 #ifdef __HIPCC__
+__host__ __device__ __forceinline__ unsigned long long *pgx_dbg(int *status) { return reinterpret_cast<unsigned long long *>(status + PGX_DBG_OFF); }
 __device__ __forceinline__ void pgx_xcd_map(int lin, int nblk, int F, int &f, int &b)
 {
     const int F8 = (F >> 3) << 3;

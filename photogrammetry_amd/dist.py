@@ -148,7 +148,11 @@ class ShardedSequence:
         self.counts_all = torch.zeros(G * self.fs, **i32)
         self.out_bufs = [torch.zeros((G * self.ps, nkp, 3), **i32) for _ in range(2 if (self.overlap and G > 1) else 1)]
         self._cur = 0
-        self._agreed = False   # the ranks have agreed once that the first step's local part went through (see step)
+        # the ranks have agreed that the local part of a step with THIS key went through (see front).  The key holds only what
+        # is equal on every rank by construction -- slot counts, image size, capacity -- never this rank's share of the work
+        # or its own error state: whether the status exchange runs must be the same decision on every rank
+        # (pgx_sequence_step_dev takes it the same way, with the context's configuration epoch as part of the key)
+        self._agreed_key = None
         self.out_all = self.out_bufs[0]
         self.kp_l = torch.zeros((self.fs, nkp, 4), **i32)
         self.nraw_l = torch.zeros(self.fs, **i32)
@@ -189,7 +193,7 @@ class ShardedSequence:
                           self.nkp, max(1, len(self.trk_frames)), self.trk["max_dist"], self.trk["min_len"], self.track_of,
                           self.trk_offsets, self.trk_nodes, self.trk_summary, d_frame_ids=self.trk_frame_ids)
 
-    def step(self, d_frames_local, after=None):
+    def step(self, d_frames_local, after=None, n_local=None):
         """d_frames_local: uint16 [len(my_frames)][H][W][4] resident on this rank's GPU.
         after = (engine, detect_stage, match_stage): another job's engine on the same GPU (two jobs kept in flight, each on its
         own stream) and the stages of ITS most recent step that this step's detect chain / matcher wait for (PGX_STAGE_* or
@@ -212,14 +216,16 @@ class ShardedSequence:
                 self.trk_counts[0].copy_(self.counts_all)
                 self._build_tracks(0)
             return
-        self.front(d_frames_local, after)
+        self.front(d_frames_local, after, n_local)
         self.back(after)
 
-    def front(self, d_frames_local, after=None):
-        """Phases 1 and 2: detect this rank's frames, gather the descriptor records (comm = "torch")."""
+    def front(self, d_frames_local, after=None, n_local=None):
+        """Phases 1 and 2: detect this rank's frames, gather the descriptor records (comm = "torch").
+        n_local: detect only the first n_local of this rank's frames (a short last batch on one rank; the other slots keep
+        what they held) -- a rank-local quantity that must not change which collectives are issued."""
         import contextlib
         assert self.comm == "torch"
-        nf = len(self.my_frames)
+        nf = len(self.my_frames) if n_local is None else max(0, min(int(n_local), len(self.my_frames)))
         other, gate_detect, _ = after if after is not None else (None, None, None)
         if other is not None and gate_detect is not None and self.on_gpu:
             self.e.wait_stage(other, gate_detect)
@@ -229,16 +235,18 @@ class ShardedSequence:
             # waiting in the all-gather: the first step ends its local part with a one-word status exchange, and every rank
             # raises if any rank failed.  Later steps with the same buffers cannot fail that way and skip the exchange (it
             # would cost a host synchronisation per step).
+            key = (self.fs, self.ps, self.W, self.H, self.nkp, self.words)
+            agreed = self._agreed_key == key
             local_error = None
             try:
                 if nf:
                     self.e.detect_batch_dev(d_frames_local, nf, self.W, self.H, self.kp_l, self.desc_l, self.counts_l,
                                             self.nraw_l, self.nkp)
             except Exception as ex:  # noqa: BLE001 -- whatever it is, the peers have to hear about it
-                if self.world == 1 or self._agreed:
-                    raise
+                if self.world == 1 or agreed:
+                    raise   # under an agreed key the peers issue the step's gathers, not a status exchange: the host must stop the job
                 local_error = ex
-            if self.world > 1 and not self._agreed:
+            if self.world > 1 and not agreed:
                 st = torch.full((1,), 0 if local_error is None else 1, dtype=torch.int32, device=self.desc_all.device)
                 st_all = torch.zeros(self.world, dtype=torch.int32, device=self.desc_all.device)
                 dist.all_gather_into_tensor(st_all, st, group=self.group)
@@ -247,7 +255,7 @@ class ShardedSequence:
                     raise local_error
                 if bad:
                     raise RuntimeError("rank(s) %s failed before the first exchange; no collective was started" % bad)
-                self._agreed = True
+                self._agreed_key = key
             if self.world > 1:
                 dist.all_gather_into_tensor(self.desc_all, self.desc_l, group=self.group)
                 dist.all_gather_into_tensor(self.counts_all, self.counts_l, group=self.group)
@@ -262,8 +270,8 @@ class ShardedSequence:
             out_all = self.out_bufs[self._cur]
             lo_p = self.rank * self.ps
             out_l = out_all[lo_p:lo_p + self.ps]
-            if other is not None and gate_match is not None and self.on_gpu:
-                self.e.gate_match(other, gate_match)   # inside the matcher call, behind its init kernel
+            if other is not None and gate_match is not None and self.on_gpu and npr:
+                self.e.gate_match(other, gate_match)   # inside the matcher call, behind its init kernel (one shot: armed only when that call follows)
             if npr:
                 self.e.match_batch_dev(self.desc_all, self.counts_all, self.nkp, self.words, self.pairlist_l, npr,
                                        out_l, max_count=self.nkp)

@@ -385,3 +385,44 @@ def test_rank_failing_before_the_first_exchange_fails_every_rank(world, bad_rank
     for r in range(world):
         if r != bad_rank:
             assert results[r].startswith("RuntimeError: rank(s) [%d] failed before the first exchange" % bad_rank), results[r]
+
+
+def _short_batch_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pairs = cref.gaussian_pairs(0, 20, 256)
+        fr = _frames()
+        pl = pdist.all_pairs(N_FRAMES)
+        job = pdist.ShardedSequence(_OracleEngine(pairs), W, H, N_FRAMES, pl, CAP, 8, "cpu")
+        mine = torch.from_numpy(np.stack([fr[f] for f in job.my_frames]))
+        job.step(mine)
+        # second step: the LAST rank's batch is one frame short (its other slots keep the first step's records); the ranks
+        # must still issue the same collectives -- the whole test would hang otherwise
+        job.step(mine, n_local=len(job.my_frames) - 1 if rank == world - 1 else None)
+        job.step(mine)
+        out = np.stack([job.matches(p).numpy() for p in range(len(pl))])
+        q.put((rank, job.counts(), out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_rank_whose_local_share_changes_issues_the_same_collectives(world):
+    """ADVICE r4 (pgx_comm.hip / dist.py): the status exchange before the first collective must be decided from rank-symmetric
+    state only.  One rank's local frame count changes between steps; nobody may hang and the results stay the single-process ones."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_short_batch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    desc, counts, pl, matches = _single_process()
+    for rank, c, m in results:
+        assert (c == counts).all() and (m == matches).all(), rank
