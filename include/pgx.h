@@ -101,7 +101,7 @@ int pgx_set_detect_params(pgx_ctx *ctx, float threshold, int suppression_radius)
 int pgx_set_capacity(pgx_ctx *ctx, int max_raw_per_frame, int max_keypoints_per_frame);
 /* Image pairs per workspace chunk of pgx_match_batch_dev / pgx_sequence_step_dev (default 2048, [16, 4096]).  A job with
  * more pairs goes through in chunks; the chunk bounds the matcher's workspace (about 4.4 MiB per image pair at 4096 descriptors
- * a side -- 4 MiB of it the residual's distance matrix: 9 GB at the default).  Chunks of 1024 pairs or more run one after the
+ * a side -- 4 MiB of it the residual's distance matrix -- plus the allocator's 25 % slack: 11 GB at the default).  Chunks of 1024 pairs or more run one after the
  * other on the context's stream with ONE workspace; smaller chunks run their stages side by side on three streams with three
  * workspaces resident (the form for small-memory configurations: it hides nothing once a chunk fills the chip).
  * The per-pair finish is one workgroup per pair, so large chunks balance the CUs better.  Results do not depend on it. */
@@ -170,11 +170,18 @@ int pgx_match_batch_dev(pgx_ctx *ctx, const uint32_t *d_desc, const int32_t *d_c
  * stream waits until stage `stage` of `other`'s most recent call of that kind has finished on the device (no wait if it has
  * run none): PGX_STAGE_DETECT = the detect chain of pgx_detect_batch_dev; PGX_STAGE_MATCH_WIDE / _ROWS / _DONE = the whole-chip
  * distance rounds / the residual distance rows / everything of pgx_match_batch_dev (the stages of pgx_sequence_step_dev count
- * the same way).  Use: pgx_wait_stage(ctx, other, PGX_STAGE_MATCH_WIDE) before ctx's pgx_detect_batch_dev of job k + 1 places
- * that detect chain -- bound by memory and cache requests -- beside job k's residual rows and per-pair finish -- bound by
- * vector instruction issue -- instead of beside the distance kernel, which it would only slow down.  The reference has the
- * same shape on the CPU: ApplyDistortionMat of image k + 1 runs beside Detect of image k (TestService.cs:25,146-149).
- * Ordering only: results do not depend on it. */
+ * the same way).  What the measurements say ("Two jobs in flight"; bench.py --gate): the productive overlap is job
+ * k + 1's detect chain BESIDE job k's distance kernel -- that kernel's 256-thread workgroups mix with the detect chain's, the
+ * two together advance at 1.15x -- so job k + 1's pgx_detect_batch_dev needs NO wait at all, and its matcher is held back with
+ * pgx_gate_match(ctx, other, PGX_STAGE_MATCH_DONE) until job k's matcher is done (two distance kernels at once, or a detect
+ * chain beside the per-pair finish, whose 512/1024-thread workgroups do not get back onto a CU that small workgroups have
+ * taken, measured slower than running them in order).  pgx_wait_stage remains for hosts that want another order.  The
+ * reference has the same shape on the CPU: ApplyDistortionMat of image k + 1 runs beside Detect of image k
+ * (TestService.cs:25,146-149).  Ordering only: results do not depend on it.
+ * Memory: every context owns its workspaces.  The matcher's is about 5.5 MiB per image pair of a chunk at 4096 descriptors a
+ * side (4 MiB of it the residual's byte matrix; allocations carry 25 % slack): 11 GB at the default chunk of 2048 pairs, so two
+ * contexts in flight hold 22 GB plus their own output buffers -- sized for the 288 GB of an MI355X; pgx_set_match_chunk
+ * lowers it. */
 enum { PGX_STAGE_DETECT = 0, PGX_STAGE_MATCH_WIDE = 1, PGX_STAGE_MATCH_ROWS = 2, PGX_STAGE_MATCH_DONE = 3 };
 int pgx_wait_stage(pgx_ctx *ctx, pgx_ctx *other, int stage);
 /* The same wait, placed INSIDE ctx's next matcher call (pgx_match_batch_dev / pgx_sequence_step_dev; one shot): between its

@@ -17,7 +17,18 @@ internal static unsafe class PgxNative
     private const string Lib = "pgx"; // libpgx.so next to the executable or on LD_LIBRARY_PATH
 
     public const int Ok = 0, EDimMismatch = 1, EOobSource = 2, EEmptySet = 3, ECapacity = 4, EBadArg = 5, EHip = 6,
-        ENotConfigured = 7, ERccl = 8;   // include/pgx.h:37-45
+        ENotConfigured = 7, ERccl = 8;   // include/pgx.h: PGX_OK, PGX_E_*
+    public const int DistNone = int.MaxValue;                                             // PGX_DIST_NONE
+    public const int SrcRgba64 = 0, SrcRgba8 = 1;                                         // PGX_SRC_*
+    public const int StageDetect = 0, StageMatchWide = 1, StageMatchRows = 2, StageMatchDone = 3;   // PGX_STAGE_*
+    public const int CommIdBytes = 128;                                                   // PGX_COMM_ID_BYTES
+
+    // Exports of include/pgx.h that this binding deliberately leaves out (tests/test_csharp_binding.py holds the list to the
+    // header): the caller's-HIP-stream hook and the measurement hooks (a managed host owns no hipStream_t and reads no HIP event
+    // times), the version string, the communicator query, and the two host-side helpers whose managed originals the host
+    // keeps (Utils.NextGaussianPair, DeWarp.GetDistortionMatrix).
+    // OMITTED: pgx_version pgx_set_stream pgx_comm_info pgx_profile_enable pgx_profile_filter pgx_profile_get pgx_profile_reset
+    // OMITTED: pgx_profile_serialize pgx_match_stats pgx_debug_counters pgx_make_brief_pairs pgx_build_dewarp_map
 
     [DllImport(Lib)] public static extern int pgx_ctx_create(int device, out IntPtr ctx);
     [DllImport(Lib)] public static extern void pgx_ctx_destroy(IntPtr ctx);
@@ -67,6 +78,11 @@ internal static unsafe class PgxNative
     [DllImport(Lib)] public static extern int pgx_tracks_add_pair(IntPtr tracks, int frameA, int frameB, PgxPair* matches, int n, int maxDist);
     [DllImport(Lib)] public static extern int pgx_tracks_finish(IntPtr tracks, int minLen, out int nTracks, out int nNodes);
     [DllImport(Lib)] public static extern int pgx_tracks_get(IntPtr tracks, int* trackOffsets, int* nodes);
+    [DllImport(Lib)] public static extern int pgx_tracks_dropped(IntPtr tracks, out int nComponents, out int nNodes);
+    // the same graph built on the device over the lists where the matcher / the all-gather left them
+    [DllImport(Lib)] public static extern int pgx_tracks_dev(IntPtr ctx, void* dMatches, void* dCounts, void* dPairlist, int m, int f, int stride,
+                                                             void* dFrameIds, int nFrames, int maxDist, int minLen, void* dTrackOf,
+                                                             void* dOffsets, void* dNodes, void* dSummary);
 
     /// <summary>Maps a status code back to the exception type the managed implementation throws.</summary>
     public static void Check(IntPtr ctx, int rc)

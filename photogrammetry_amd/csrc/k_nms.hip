@@ -1529,8 +1529,9 @@ __global__ __launch_bounds__(NT) void k_nms_tail(const int32_t *raw_score_all,
 // mask rounds continued by one workgroup per frame on a compact list of the cells whose champion entry is not zero yet
 // (open cells, plus closed ones that still have to take their stale entry down), a block barrier in place of the kernel
 // boundary; then the output order.
-// 256 threads and 64 KiB of LDS: one wave per SIMD at <= 128 registers, so that a workgroup finds room on a CU that still
-// runs a distance-kernel workgroup of another job (240 registers per wave, 35 KiB of LDS).  With 1024 threads x 121
+// 512 threads and 64 KiB of LDS: two waves per SIMD at <= 128 registers, so that a workgroup finds room on a CU that still
+// runs ONE distance-kernel workgroup of another job (240 registers per wave, 35 KiB of LDS; 256 threads were measured too:
+// `nms` 0.54 ms per step against 0.49).  With 1024 threads x 121
 // registers and 128 KiB it needed a completely EMPTY CU, which never happens while the other job's distance kernel has
 // workgroups waiting: the whole detect chain of a second job in flight stalled here until that launch had drained (2.5 ms
 // instead of 0.1).  The rounds work on a few hundred listed cells, the order pass on 15 k bitmap words: alone it is as fast.

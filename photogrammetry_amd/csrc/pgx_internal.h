@@ -97,7 +97,7 @@ struct pgx_ctx {
     // image pairs per matcher workspace chunk (pgx_set_match_chunk).  The per-pair finish is one workgroup per image pair, and
     // the pairs of a sequence differ 3:1 in how long they take: the more of them one launch holds, the better the CUs are
     // balanced (stand-alone finish of the bench job's 2016 pairs: 2.15 ms at 256 pairs per chunk, 1.70 at 512, 1.24 in one
-    // chunk; whole matcher 6.58 / 6.43 / 6.00 ms).  4.4 MiB of workspace per pair: 9 GB at the default.
+    // chunk; whole matcher 6.58 / 6.43 / 6.00 ms).  4.4 MiB of workspace per pair (+ 25 % slack of DevBuf::ensure): 11 GB at the default.
     int match_chunk = 2048;
     int src8 = 0; // pgx_set_source_format: 1 = the rgba arguments are 8-bit RGBA
 
