@@ -36,10 +36,17 @@
 namespace {
 
 constexpr int TRK_NT = 256;          // threads per workgroup of the per-entry / per-node kernels
-constexpr int SCAN_NT = 1024;        // scan kernels: 1024 threads x 4 items
+constexpr int SCAN_NT = 256;         // scan kernels: 256 threads x 4 items.  Small on purpose: a 1024-thread workgroup needs 4 free wave
+                                     // slots on every SIMD of one CU at once, and beside another job's distance kernel it waited
+                                     // 3 ms for them (the one-workgroup k_trk_scan_sums, kernel trace of round 5)
 constexpr int SCAN_ITEMS = 4 * SCAN_NT;
 constexpr uint32_t TRK_EMPTY = 0xFFFFFFFFu;
 constexpr int TRK_ECNT = 256;        // slots of the edge counter
+// Workgroups of k_trk_union (grid-stride over the match entries).  The bench job's graph alone, ms per call: 32 workgroups 2.79,
+// 64: 1.45, 128: 0.82, 192: 0.62, 256: 0.55, 512: 0.59, 1024: 0.65, 2048: 0.81, 4096: 0.90, one per 256 entries (32 k): 0.70 --
+// fewer threads in flight see fresher trees and lose fewer CAS, too few leave the dependent L2 reads uncovered; one per CU it is
+constexpr int TRK_UNION_GRID = 256;
+static_assert(TRK_ECNT <= SCAN_NT, "k_trk_scan_sums adds the edge-counter slots up in one block scan");
 constexpr int FL_SLOTS = 512;        // LDS aggregation table of k_trk_flatten (>= 2 * TRK_NT)
 
 struct TrkArgs {
@@ -105,12 +112,12 @@ __global__ __launch_bounds__(TRK_NT) void k_trk_init(TrkArgs a)
     if (t0 < TRK_ECNT) a.ecnt[t0] = 0;
 }
 
-// The gated edge of this thread's match entry: workgroup -> (image pair, chunk of its list), thread -> entry.  False for the
+// The gated edge of this thread's match entry: work item -> (image pair, chunk of its list), thread -> entry.  False for the
 // whole workgroup when the pair names a slot outside the graph.
-__device__ __forceinline__ bool trk_edge(const TrkArgs &a, int &u, int &v)
+__device__ __forceinline__ bool trk_edge(const TrkArgs &a, long long item, int &u, int &v)
 {
     const int chunks = (a.stride + TRK_NT - 1) / TRK_NT;
-    const int m = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const int m = (int)(item / chunks), ch = (int)(item % chunks);
     const int sa = a.pairlist[2 * m], sb = a.pairlist[2 * m + 1];
     if ((unsigned)sa >= (unsigned)a.F || (unsigned)sb >= (unsigned)a.F) return false;
     const int fa = fid_of(a, sa), fb = fid_of(a, sb);
@@ -127,27 +134,34 @@ __device__ __forceinline__ bool trk_edge(const TrkArgs &a, int &u, int &v)
     return p.dist <= a.max_dist && p.dist != PGX_DIST_NONE && (unsigned)p.k1 < (unsigned)ca && (unsigned)p.k2 < (unsigned)cb;
 }
 
-// Lock-free union of every edge's two trees.  grid: M * ceil(stride / TRK_NT) workgroups
-__global__ __launch_bounds__(TRK_NT) void k_trk_union(TrkArgs a)
+// Lock-free union of every edge's two trees.  Work items = M * ceil(stride / TRK_NT) chunks of TRK_NT match entries, taken
+// grid-stride by a bounded grid (pgx_launch_tracks): the kernel is latency-bound on dependent L2 reads and atomics, and a
+// flood of 32 k tiny workgroups takes every wave slot that comes free on the chip -- another job's distance kernel (240
+// registers per wave) then never gets its second wave per SIMD back (bench step 7.2 -> 8.2 ms for a 0.8 ms graph).
+__global__ __launch_bounds__(TRK_NT) void k_trk_union(TrkArgs a, long long n_items)
 {
-    int u = 0, v = 0;
-    const bool edge = trk_edge(a, u, v);
-    // edges used: the count goes through LDS and then into one of TRK_ECNT slots; k_trk_scan_sums adds them up
+    int mine = 0;   // edges used, counted by lane 0 of every wave
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        int u = 0, v = 0;
+        const bool edge = trk_edge(a, item, u, v);
+        const unsigned long long bal = __ballot(edge);
+        mine += __popcll(bal);
+        if (!edge) continue;
+        int ru = trk_find(a.parent, u), rv = trk_find(a.parent, v);
+        while (ru != rv) {
+            if (trk_prio(ru) < trk_prio(rv)) { const int t = ru; ru = rv; rv = t; }   // ru hooks under rv
+            const int old = atomicCAS(a.parent + ru, ru, rv);
+            if (old == ru) break;
+            ru = trk_find(a.parent, old);   // ru was no root any more: go on from the root above its true parent
+        }
+    }
+    // edges used: through LDS into one of TRK_ECNT slots (same-address atomics serialise); k_trk_scan_sums adds them up
     __shared__ int n_edges;
     if (threadIdx.x == 0) n_edges = 0;
     __syncthreads();
-    const unsigned long long bal = __ballot(edge);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&n_edges, __popcll(bal));
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&n_edges, mine);
     __syncthreads();
     if (threadIdx.x == 0 && n_edges) atomicAdd(a.ecnt + (blockIdx.x & (TRK_ECNT - 1)), n_edges);
-    if (!edge) return;
-    int ru = trk_find(a.parent, u), rv = trk_find(a.parent, v);
-    while (ru != rv) {
-        if (trk_prio(ru) < trk_prio(rv)) { const int t = ru; ru = rv; rv = t; }   // ru hooks under rv
-        const int old = atomicCAS(a.parent + ru, ru, rv);
-        if (old == ru) break;
-        ru = trk_find(a.parent, old);   // ru was no root any more: go on from the root above its true parent
-    }
 }
 
 // grid: F * ceil(stride / TRK_NT); workgroup -> (slot, chunk of its keypoints)
@@ -400,7 +414,9 @@ void pgx_launch_tracks(hipStream_t s, const pgx_pair *d_matches, const int32_t *
     if (gi < 1) gi = 1;
     hipLaunchKernelGGL(k_trk_init, dim3((unsigned)gi), dim3(TRK_NT), 0, s, a);
     if (M > 0) {
-        hipLaunchKernelGGL(k_trk_union, dim3((unsigned)((size_t)M * chunks)), dim3(TRK_NT), 0, s, a);
+        const long long n_items = (long long)M * chunks;
+        const long long gu = n_items < TRK_UNION_GRID ? n_items : TRK_UNION_GRID;
+        hipLaunchKernelGGL(k_trk_union, dim3((unsigned)gu), dim3(TRK_NT), 0, s, a, n_items);
     }
     if (F > 0) hipLaunchKernelGGL(k_trk_flatten, dim3((unsigned)((size_t)F * chunks)), dim3(TRK_NT), 0, s, a);
     const int nb = (int)((a.N + SCAN_ITEMS - 1) / SCAN_ITEMS);

@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 GROUPS = (("k_ham", "ham"), ("k_tail_rows", "rows"), ("k_match_gs", "finish"), ("k_match_finish", "finish"), ("k_match_select", "select"),
-          ("k_match_init", "init"), ("k_dewarp", "detect"), ("k_fast", "detect"), ("k_nms", "detect"), ("k_brief", "detect"))
+          ("k_match_init", "init"), ("k_trk", "tracks"), ("k_dewarp", "detect"), ("k_fast", "detect"), ("k_nms", "detect"), ("k_brief", "detect"))
 
 
 def group(name):
