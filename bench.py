@@ -568,20 +568,26 @@ def worker(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t[0].item())
     if args.sustain_s > 0:
-        n_sus = max(NI, int(args.sustain_s / max(dt_max / args.steps, 1e-6)) + 1)
         for e in engs:
             e.profile_reset()
             e.profile_filter("ham_argmin")
             e.profile_enable(not args.no_profile)   # the same instrumentation as the headline region
         barrier()
         t0 = time.perf_counter()
-        run_steps(n_sus)
-        for j in jobs:
-            j.finish()
-        barrier()
-        ts = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        n_sus, n_next = 0, max(NI, int(args.sustain_s / max(dt_max / args.steps, 1e-6)) + 1)
+        while True:   # normally one stretch; a second one if the headline rate (a few steps, pipeline fill included) overestimated the step
+            run_steps(n_next)
+            for j in jobs:
+                j.finish()
+            barrier()
+            n_sus += n_next
+            ts = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)   # every rank takes the same decision
+            el = float(ts[0].item())
+            if el >= args.sustain_s or n_sus > 200000:
+                break
+            n_next = max(NI, int((args.sustain_s - el) * 1.1 / (el / n_sus)) + 1)
         for e in engs:
             e.profile_enable(False)
             e.profile_filter(None)
