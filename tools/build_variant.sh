@@ -9,6 +9,6 @@ mkdir -p $root/build/variants /tmp/pgx_var_$name
 make -s -C $cs >/dev/null
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function "$@" -c $cs/k_match.hip -o /tmp/pgx_var_$name/k_match.o
 objs=""
-for o in pgx_api pgx_comm k_image k_fast k_nms k_brief k_pose pgx_hostutil pgx_tracks; do objs="$objs $cs/$o.o"; done
+for o in pgx_api pgx_comm k_image k_fast k_nms k_brief k_pose k_tracks pgx_hostutil pgx_tracks; do objs="$objs $cs/$o.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/build/variants/libpgx_$name.so $objs /tmp/pgx_var_$name/k_match.o -ldl
 echo built $root/build/variants/libpgx_$name.so
