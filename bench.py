@@ -919,6 +919,21 @@ def extra_configs(torch, pg, pdist, np, eng, dev, stream, pairs_tbl, dmap):
             c = cnt.cpu().numpy()
             npairs = float(sum(int(c[a]) * int(c[b]) for a, b in pl_h))
             _, evals, _ = e4.match_stats()
+            # the track graph of those lists at this size (8.4 M nodes, 133 M match entries): pgx_tracks_dev on the resident buffers
+            trk_of = torch.zeros((F4, NKP4), **i32)
+            trk_off, trk_nodes, trk_sum = torch.zeros(F4 * NKP4 + 1, **i32), torch.zeros((F4 * NKP4, 2), **i32), torch.zeros(8, **i32)
+
+            def trk4():
+                e4.tracks_dev(outp, cnt, pl, len(pl_h), F4, NKP4, F4, TRACK_MAX_DIST, 2, trk_of, trk_off, trk_nodes, trk_sum)
+            tt = _timed(torch, trk4, 2)
+            e4.check_status()
+            ts = trk_sum.cpu().tolist()
+            tracks4 = {"s": tt, "match_entries_per_s": len(pl_h) * NKP4 / tt, "n_tracks": ts[0], "n_nodes": ts[1], "dropped": ts[2],
+                       "dropped_nodes": ts[3], "edges": ts[4], "longest": ts[5], "largest_dropped": ts[6],
+                       "consistent": bool(int(trk_off[ts[0]].item()) == ts[1] and int((trk_of >= 0).sum().item()) == ts[1]
+                                          and int((trk_of == -2).sum().item()) == ts[3]),
+                       "max_dist": TRACK_MAX_DIST}
+            del trk_of, trk_off, trk_nodes
             out["config4_window16"] = {
                 "workload": "BASELINE configs[3], one-GPU window variant (SURVEY 8d config 4): 1024 x 3840x2160 frames made on the device, "
                             "image pairs 0 < j - i <= 16 (%d), r = %d, <=%d keypoints per frame" % (len(pl_h), R4, NKP4),
@@ -926,7 +941,8 @@ def extra_configs(torch, pg, pdist, np, eng, dev, stream, pairs_tbl, dmap):
                 "match_pairs_per_s": npairs / tm, "end_to_end_pairs_per_s": npairs / (td + tm),
                 "keypoints_min_max": [int(c.min()), int(c.max())],
                 "kernels_ms": {k: v["ms_per_step"] for k, v in kern.items()},
-                "mfma_frac": (evals * 2.0 * P / (kern["ham_argmin"]["ms_per_step"] * 1e-3) / I8_MFMA_PEAK_OPS) if "ham_argmin" in kern else None}
+                "mfma_frac": (evals * 2.0 * P / (kern["ham_argmin"]["ms_per_step"] * 1e-3) / I8_MFMA_PEAK_OPS) if "ham_argmin" in kern else None,
+                "tracks": tracks4}
             del d_frames, d_base, kp, desc, cnt, nraw, outp
     finally:
         e4.close()
