@@ -8,11 +8,11 @@ REPO=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # counter passes: one job at a time (the profiler serialises dispatches anyway; per-kernel attribution stays clean)
-BENCH="python3 $REPO/bench.py --no-extra-configs --no-cpu-baseline --steps 3 --warmup 1 --in-flight 1"
+BENCH="python3 $REPO/bench.py --no-extra-configs --no-cpu-baseline --steps 3 --warmup 1 --in-flight 1 --sustain-s 0"
 WANT=" ${PASSES:-stats fetch write tcp tcc ta sq mfma} "
 want() { [[ "$WANT" == *" $1 "* ]]; }
 if want stats; then
-    timeout -k 5 240 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- python3 $REPO/bench.py --no-extra-configs --no-cpu-baseline --no-standalone-pass --steps 30 > "$OUT/stats_bench.json" 2> "$OUT/stats.err" || echo "stats pass failed"
+    timeout -k 5 240 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- python3 $REPO/bench.py --no-extra-configs --no-cpu-baseline --no-standalone-pass --sustain-s 0 --steps 30 > "$OUT/stats_bench.json" 2> "$OUT/stats.err" || echo "stats pass failed"
     echo "stats done $(date +%T)" | tee -a "$OUT/progress.log"
 fi
 pass() { # name, counters...   (a pass that asks for more counters than a block has slots aborts: keep each set small)

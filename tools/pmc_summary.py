@@ -22,7 +22,7 @@ from collections import defaultdict
 GROUPS = [("k_dewarp_gray", "dewarp_gray"), ("k_fast_planes", "fast"), ("k_seg_scan", "fast"), ("k_fast_compact", "fast"),
           ("k_nms", "nms"), ("k_brief", "brief"), ("k_ham_mfma", "ham_argmin"), ("k_ham_fp4", "ham_argmin"), ("k_ham_valu", "ham_argmin"),
           ("k_match_select", "match_select"), ("k_tail_rows", "tail_rows"), ("k_match_gs", "match_finish"),
-          ("k_match_finish", "match_finish"), ("k_match_init", "match_init")]
+          ("k_match_finish", "match_finish"), ("k_match_init", "match_init"), ("k_match_order", "match_finish"), ("k_trk_", "tracks")]
 DETECT = ("dewarp_gray", "fast", "nms", "brief")
 
 
