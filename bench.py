@@ -60,7 +60,7 @@ SEQ_FRAMES = 64
 MFMA_FP4 = True
 I8_MFMA_PEAK_OPS = 10.0e15   # name kept from round 1: operations of the 256-bit +-1 contraction per second (dense FP4 peak)
 HBM_PEAK = 8.0e12
-TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r05_traffic.json")
 TRACK_MAX_DIST = 64   # the gate of the track graph: the reference's matchers took one (match_keypoints.py:23 default 75 on its own
                       # descriptors; `new KeypointMatching(100)`, Program.cs:165); forced assignments of the greedy matcher on
                       # 256-bit BRIEF sit near 100-128, true correspondences of the translated frames near 0
