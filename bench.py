@@ -94,11 +94,13 @@ def parse_args(argv=None):
                     help="jobs kept in flight: consecutive steps alternate between this many contexts (each with its own stream, buffers and "
                          "workspaces); with 2 (default) the detect chain of step k + 1 runs beside the distance kernel of step k "
                          "(round 4, same box: 7.43 ms per step against 8.04 with one job at a time); 1 = strictly one job at a time")
-    ap.add_argument("--gate", default="none,done",
+    ap.add_argument("--gate", default="none,rows",
                     help="--in-flight >= 2: DETECT,MATCH = the stages of the previous job that a job's detect chain / matcher wait for "
-                         "(pgx_wait_stage; each one of none, detect, wide, rows, done).  Default none,done: the matcher of step k + 1 starts "
-                         "when step k's is done (the per-pair finish gains nothing from company, 1024-thread workgroups do not mix), its "
-                         "detect chain as soon as its stream gets to it, i.e. beside step k's distance kernel.  none,none: the GPU "
+                         "(pgx_wait_stage; each one of none, detect, wide, rows, done).  Default none,rows (round 5): the distance kernel of "
+                         "step k + 1 starts when step k's residual rows are written, i.e. beside step k's per-pair finish and track graph, "
+                         "and its detect chain as soon as its stream gets to it (beside step k's distance kernel): 7.13 ms per step against "
+                         "7.21 with none,done (round 4's default: the matcher of step k + 1 waits for all of step k's; three interleaved "
+                         "runs each, same box); none,wide (the residual rows beside the next distance kernel too) 7.49.  none,none: the GPU "
                          "interleaves the jobs as it likes")
     ap.add_argument("--c-abi-comm", action="store_true",
                     help="N > 1: after the timed region, run the same job once more through the C ABI's own RCCL communicator "
@@ -484,8 +486,9 @@ def worker(args):
         to cross the links).  Exactly n fronts and n backs are issued; at N = 1 there is no collective and the order of issue
         changes nothing on the device."""
         def gates(s):
-            # step s runs on job s % NI; its gates refer to the previous step's job.  Default none,done: the matcher of step s
-            # starts when step s - 1's is done, its detect chain as soon as its stream gets to it (beside that distance kernel)
+            # step s runs on job s % NI; its gates refer to the previous step's job.  Default none,rows: the distance kernel of step s
+            # starts when step s - 1's residual rows are done (beside its per-pair finish), its detect chain as soon as its stream
+            # gets to it (beside step s - 1's distance kernel)
             return (engs[(s - 1) % NI],) + GATES if (NI > 1 and s > 0) else None
         if NI == 1 or GATES[0] is not None:   # a detect gate names a stage of the PREVIOUS step's matcher call: keep whole steps in order
             for s in range(n):

@@ -171,11 +171,12 @@ int pgx_match_batch_dev(pgx_ctx *ctx, const uint32_t *d_desc, const int32_t *d_c
  * run none): PGX_STAGE_DETECT = the detect chain of pgx_detect_batch_dev; PGX_STAGE_MATCH_WIDE / _ROWS / _DONE = the whole-chip
  * distance rounds / the residual distance rows / everything of pgx_match_batch_dev (the stages of pgx_sequence_step_dev count
  * the same way).  What the measurements say ("Two jobs in flight"; bench.py --gate): the productive overlap is job
- * k + 1's detect chain BESIDE job k's distance kernel -- that kernel's 256-thread workgroups mix with the detect chain's, the
- * two together advance at 1.15x -- so job k + 1's pgx_detect_batch_dev needs NO wait at all, and its matcher is held back with
- * pgx_gate_match(ctx, other, PGX_STAGE_MATCH_DONE) until job k's matcher is done (two distance kernels at once, or a detect
- * chain beside the per-pair finish, whose 512/1024-thread workgroups do not get back onto a CU that small workgroups have
- * taken, measured slower than running them in order).  pgx_wait_stage remains for hosts that want another order.  The
+ * k + 1's detect chain BESIDE job k's distance kernel -- that kernel's 256-thread workgroups mix with the detect chain's -- so job
+ * k + 1's pgx_detect_batch_dev needs NO wait at all, and its matcher is held back with
+ * pgx_gate_match(ctx, other, PGX_STAGE_MATCH_ROWS) until job k's residual distance rows are written: the next distance kernel
+ * then runs beside job k's per-pair finish (round 5: 7.13 ms per bench step; waiting for PGX_STAGE_MATCH_DONE 7.21, for
+ * PGX_STAGE_MATCH_WIDE only -- the rows kernel beside the next distance kernel, both on the matrix pipe -- 7.49; no gate at all:
+ * two distance kernels at once, slower still).  pgx_wait_stage remains for hosts that want another order.  The
  * reference has the same shape on the CPU: ApplyDistortionMat of image k + 1 runs beside Detect of image k
  * (TestService.cs:25,146-149).  Ordering only: results do not depend on it.
  * Memory: every context owns its workspaces.  The matcher's is about 5.5 MiB per image pair of a chunk at 4096 descriptors a
