@@ -449,9 +449,9 @@ def test_match_sizes_beyond_the_bench(engine, n1, n2, kind):
         assert int((got["dist"] == pg.api.PGX_DIST_NONE).sum()) == n1 - n2
 
 
-@pytest.mark.parametrize("gates,chunk", [((None, 3), 2048), ((1, None), 2048), ((2, 3), 2048), ((0, 1), 2048), ((None, 3), 16), ((1, 2), 16)])
+@pytest.mark.parametrize("gates,chunk", [((None, 2), 2048), ((None, 3), 2048), ((1, None), 2048), ((2, 3), 2048), ((0, 1), 2048), ((None, 3), 16), ((1, 2), 16)])
 def test_two_jobs_in_flight_with_stage_gates_equal_one_job(engine, gates, chunk):
-    """bench.py's default form: two contexts, two streams, consecutive steps alternate between them and pgx_wait_stage orders
+    """bench.py's default form ((None, 2) = --gate none,rows): two contexts, two streams, consecutive steps alternate between them and pgx_wait_stage orders
     a step's detect chain / matcher behind stages of the previous step on the OTHER context (PGX_STAGE_*: 0 detect, 1 match
     wide, 2 match rows, 3 match done).  Ordering only: every step of either context must equal the one-job result, whatever
     the gates; frames differ between steps so that a step reading the other context's buffers would show.  chunk = 16: the 21
