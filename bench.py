@@ -30,6 +30,7 @@ Extra objects on the JSON line:
   tracks        the track graph of every step's match lists (pgx_tracks_dev): built INSIDE the timed step, on the
                 device, behind the matcher (N = 1) / behind the list gather (N > 1); counts, kernel time, and the check of
                 the timed job's graph against the sequential oracle
+  without_tracks the headline region once more with the track graph switched off (outside `value`): comparable with rounds 1-4
   sustained     the same steps again for >= 3 s right after the headline region (outside `value`): a rate the driver's
                 clock and gpu_busy samples can corroborate
   configs       (N = 1) the other BASELINE configurations on this GPU: configs[1] x 64 independent pairs,
@@ -602,6 +603,41 @@ def worker(args):
                      "value": pairs_per_step * n_sus / float(ts[0].item()),
                      "what": "the headline job again, same schedule and instrumentation, right after the headline region; not part of `value`"}
         log("[rank %d] sustained: %d steps in %.2f s = %.3f ms per step" % (rank, n_sus, sustained["seconds"], sustained["ms_per_step"]))
+    # the headline region once more WITHOUT the track graph (the same K steps, same schedule, same instrumentation): the figure that
+    # compares with the rounds before the graph joined the step (round 4: 7.17 ms at the driver's 20 steps); outside `value`
+    without_tracks = None
+    if track_cfg and args.sustain_s > 0:
+        saved = [j.trk for j in jobs]
+        for j in jobs:
+            j.trk = None
+        for e in engs:
+            e.profile_reset()
+            e.profile_filter("ham_argmin")
+            e.profile_enable(not args.no_profile)
+        run_steps(NI)   # refill nothing, just leave the graph's buffers behind
+        for j in jobs:
+            j.finish()
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        for j in jobs:
+            j.finish()
+        barrier()
+        tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        for e in engs:
+            e.profile_enable(False)
+            e.profile_filter(None)
+            e.check_status()
+            e.debug_counters()
+        for j, t_ in zip(jobs, saved):
+            j.trk = t_
+        without_tracks = {"steps": args.steps, "ms_per_step": float(tw[0].item()) / args.steps * 1e3,
+                          "value": pairs_per_step * args.steps / float(tw[0].item()),
+                          "what": "the headline region repeated with the track graph switched off (detect + match only, as in the rounds "
+                                  "before it joined the step); not part of `value`"}
+        log("[rank %d] without the track graph: %.3f ms per step" % (rank, without_tracks["ms_per_step"]))
     # stand-alone kernel times: in the timed region three matcher stages of consecutive chunks share the chip, so their
     # event brackets overlap and stretch each other; a second, untimed pass runs the same steps with the stages in order
     kern_alone, k_alone = {}, max(3, min(20, args.steps))
@@ -766,6 +802,7 @@ def worker(args):
             "roofline": rooflines.get(dominant),
             "verified": verified,
             "tracks": tracks_obj,
+            "without_tracks": without_tracks,
             "sustained": sustained,
             "mfma": mfma,
             "c_abi_comm": c_abi,

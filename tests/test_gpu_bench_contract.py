@@ -43,6 +43,9 @@ def test_bench_json_line_contract():
     # the sustained leg: the same job for about three seconds, outside `value`
     su = d["sustained"]
     assert su["steps"] >= 2 and su["seconds"] >= 3.0 and su["ms_per_step"] > 0
+    # and the headline region once more without the track graph (the figure that compares with rounds 1-4), outside `value`
+    wt = d["without_tracks"]
+    assert wt["steps"] == 3 and wt["ms_per_step"] > 0 and wt["value"] > 0
 
 
 def _rehearse(extra):
@@ -75,4 +78,4 @@ def test_default_multi_rank_path_rehearsed_on_one_gpu(scaling):
     assert d["config"]["frames_per_gpu"] == 6 * nseq and d["config"]["image_pairs_per_gpu"] == 33 * nseq
     tr = d["tracks"]
     assert tr["frames"] == 12 and tr["image_pairs"] == 66 and tr["n_tracks"] > 100   # rank 0's graph: its sequence / the one sequence
-    assert d["sustained"]["steps"] >= 2
+    assert d["sustained"]["steps"] >= 2 and d["without_tracks"]["steps"] == 3
